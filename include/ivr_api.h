@@ -1,0 +1,169 @@
+/*
+ * ivr_api.h - C ABI of libivr_hip.so: the MI355X (gfx950) implementation of the
+ * frame -> embedding -> cosine top-k hot path of
+ * DMDung2k3/Intelligent-Video-Analysis-Retrieval-System.
+ *
+ * The reference has no FFI of its own: the path sits behind duck-typed Python
+ * objects.  Each entry point below names the reference call
+ * it stands in for; paths are relative to the reference checkout.  The Python
+ * mirror of the reference classes (ivr_amd/compat.py) binds these through ctypes
+ * (ivr_amd/_ffi.py); INTEGRATION.md shows the stub a maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / numpy types.
+ *  - Every bulk pointer marked DEV is a device (HBM) pointer owned by the caller;
+ *    HOST pointers are small parameter blocks or one-time weight uploads.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
+ *    only enqueue work; nothing synchronises unless stated.
+ *  - Every function returns IVR_OK (0) or a negative ivr_status and never throws
+ *    or aborts; ivr_last_error() returns the calling thread's last message.
+ *  - Handles may be used from several host threads (the reference calls
+ *    encode_images from a 4-thread pool, unified_index.py:773): calls on one handle
+ *    are serialised by a per-handle mutex, distinct handles are independent.
+ */
+#ifndef IVR_API_H
+#define IVR_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVR_API_VERSION 1
+#define IVR_MAX_K 2048          /* reference: k=50 default, SearchOptions.limit <= 1000 (system.py:91) */
+
+typedef enum ivr_status {
+    IVR_OK = 0,
+    IVR_ERR_INVALID = -1,       /* bad argument / shape: shim raises ValueError (core.py:1178-1191) */
+    IVR_ERR_HIP = -2,           /* HIP runtime failure: shim raises RuntimeError (core.py:894-896) */
+    IVR_ERR_OOM = -3,
+    IVR_ERR_STATE = -4,         /* handle not ready (e.g. tower not finalized, index empty where rows are needed) */
+    IVR_ERR_UNSUPPORTED = -5
+} ivr_status;
+
+typedef struct ivr_ctx ivr_ctx;
+typedef struct ivr_index ivr_index;
+typedef struct ivr_tower ivr_tower;
+typedef void *ivr_stream;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int ivr_api_version(void);
+int ivr_init(int device, ivr_ctx **out);
+int ivr_destroy(ivr_ctx *ctx);
+const char *ivr_last_error(ivr_ctx *ctx);       /* ctx may be NULL */
+int ivr_device_info(ivr_ctx *ctx, int *cu_count, int64_t *hbm_bytes, char *arch, int arch_len);
+
+/* ---- P1 / P2: frame preprocessing -------------------------------------------------------------
+ * Replaces HFCLIPProcessor(images=...) at core.py:1613 and
+ * cv2.cvtColor + Image.resize + processor(...) at video_frame_filter.py:58-59,29.
+ * src: DEV uint8 [n, h, w, 3] (NHWC, dense).  Output: [n,3,S,S] (NCHW) or the patch-major
+ * im2col matrix [n*(S/P)^2, 3*P*P] (column order c,py,px = the conv weight's) that feeds the
+ * patch-embed GEMM directly.  Geometry is PIL's two-pass fixed-point resampler, bit-exact.
+ */
+enum {
+    IVR_PP_MODE_IDENTITY = 0,           /* h == w == S */
+    IVR_PP_MODE_SHORTEST_EDGE_CROP = 1, /* CLIP processor: shortest edge -> S, centre crop SxS */
+    IVR_PP_MODE_STRETCH = 2,            /* video_frame_filter.py:59 */
+    IVR_PP_MODE_LETTERBOX = 3,          /* extra (BASELINE.json wording); long edge -> S, zero canvas */
+    IVR_PP_MODE_MASK = 0xF,
+    IVR_PP_BGR = 1 << 4,                /* src is BGR (cv2) - swapped while loading */
+    IVR_PP_OUT_F32 = 1 << 5,            /* default output dtype is bf16 */
+    IVR_PP_OUT_PATCH_MAJOR = 1 << 6,    /* default layout is NCHW */
+    IVR_PP_BILINEAR = 1 << 7            /* default filter is BICUBIC (PIL default, CLIP processor) */
+};
+int ivr_preprocess(ivr_ctx *ctx, const uint8_t *src /*DEV*/, int n, int h, int w, int flags,
+                   const float mean[3] /*HOST*/, const float std[3] /*HOST*/, int out_size, int patch,
+                   void *dst /*DEV*/, ivr_stream stream);
+/* bytes of DEV scratch ivr_preprocess needs for (n,h,w,flags); 0 for identity geometry.  The scratch
+ * lives in the context and grows on demand (outside of stream capture). */
+int64_t ivr_preprocess_scratch_bytes(int n, int h, int w, int flags, int out_size);
+
+/* ---- E1 / E2 / E3 + N1: encoder towers --------------------------------------------------------
+ * Replaces CLIPModel.get_image_features + F.normalize (core.py:1619-1620),
+ * CLIPModel.get_text_features + F.normalize (core.py:1541-1542) and
+ * ViTModel(...).last_hidden_state[:,0,:] (video_frame_filter.py:31-32).
+ */
+enum { IVR_ACT_QUICK_GELU = 0, IVR_ACT_GELU_ERF = 1 };
+enum { IVR_POOL_CLS_POSTLN_PROJ = 0, IVR_POOL_LN_ALL_CLS = 1, IVR_POOL_EOS_LN_PROJ = 2 };
+enum { IVR_KIND_VISION = 0, IVR_KIND_TEXT = 1 };
+enum { IVR_COMPUTE_BF16 = 0, IVR_COMPUTE_F32 = 1 /* verification mode: f32 MFMA, f32 activations */ };
+
+typedef struct ivr_tower_desc {
+    int kind, width, layers, heads, mlp, tokens, out_dim, act, pool;
+    int image, patch, pre_ln, patch_bias;   /* vision */
+    int vocab, eos_id, causal;               /* text */
+    int compute;                             /* IVR_COMPUTE_* */
+    float ln_eps;
+} ivr_tower_desc;
+
+int ivr_tower_create(ivr_ctx *ctx, const ivr_tower_desc *desc, ivr_tower **out);
+/* name = canonical tensor name (ivr_amd/weights.py); data = HOST float32, nn.Linear layout W[out,in]. */
+int ivr_tower_set_weight(ivr_tower *t, const char *name, const float *data /*HOST*/, int64_t count);
+/* checks that every tensor was set, packs QKV, allocates the activation workspace for max_batch. */
+int ivr_tower_finalize(ivr_tower *t, int max_batch);
+int ivr_tower_destroy(ivr_tower *t);
+/* patches: DEV patch-major pixels from ivr_preprocess (bf16, or f32 for IVR_COMPUTE_F32),
+ * out: DEV float32 [n, embed_dim]; normalize=1 applies x / max(||x||, 1e-12) (F.normalize). */
+int ivr_tower_encode_image(ivr_tower *t, const void *patches /*DEV*/, int n, int normalize,
+                           float *out /*DEV*/, ivr_stream stream);
+/* ids: DEV int64 [q, T] (T <= desc.tokens); pooled at the first eos_id per row. */
+int ivr_tower_encode_text(ivr_tower *t, const int64_t *ids /*DEV*/, int q, int T, int normalize,
+                          float *out /*DEV*/, ivr_stream stream);
+/* bring-up / parity: arm a one-shot capture - the NEXT encode call copies the residual stream after
+ * `layer` blocks (0 = embeddings) into out as f32 [n,T,width]. */
+int ivr_tower_debug_hidden(ivr_tower *t, int layer, int n, float *out /*DEV*/, ivr_stream stream);
+int64_t ivr_tower_workspace_bytes(ivr_tower *t);
+
+/* ---- N2 / N3: row L2 normalisation -------------------------------------------------------------
+ * Replaces FAISSRetriever._normalize_and_validate_features (core.py:1176-1196) and
+ * faiss.normalize_L2 (unified_index.py:1776): x /= ||x||, all-zero rows stay zero.  In place.
+ * nonfinite (DEV int32, may be NULL) receives the count of NaN/Inf input elements (the shim turns
+ * a non-zero count into the ValueError of core.py:1190-1191).
+ */
+int ivr_l2_normalize(ivr_ctx *ctx, float *x /*DEV*/, int64_t n, int d, int32_t *nonfinite /*DEV*/,
+                     ivr_stream stream);
+
+/* ---- I1 + S1: flat inner-product index ---------------------------------------------------------
+ * Replaces faiss.IndexFlatIP(d) / .add / .search (unified_index.py:1767,1779,503; core.py:1208,827,891).
+ * Rows live in HBM as float32 in a 16-row x 4-float interleaved tile layout chosen so that one
+ * wave-wide 16-byte load is an MFMA operand fragment and 1 KiB contiguous.
+ */
+int ivr_index_create(ivr_ctx *ctx, int d, int64_t capacity_rows, ivr_index **out);
+int ivr_index_destroy(ivr_index *idx);
+int ivr_index_reset(ivr_index *idx);                        /* ntotal = 0 */
+int64_t ivr_index_ntotal(ivr_index *idx);
+int ivr_index_dim(ivr_index *idx);
+int64_t ivr_index_capacity(ivr_index *idx);
+/* append n rows (DEV float32 [n,d] row-major); grows the allocation when capacity is exceeded. */
+int ivr_index_add(ivr_index *idx, const float *rows /*DEV*/, int64_t n, int normalize, ivr_stream stream);
+/* overwrite rows [start, start+n) (ring-buffer use, BASELINE config 4); start+n <= ntotal. */
+int ivr_index_write(ivr_index *idx, int64_t start, const float *rows /*DEV*/, int64_t n, int normalize,
+                    ivr_stream stream);
+/* copy rows [start, start+n) back to row-major float32 (faiss reconstruct_n). */
+int ivr_index_reconstruct(ivr_index *idx, int64_t start, int64_t n, float *out /*DEV*/, ivr_stream stream);
+/* pre-size the search workspace so that ivr_index_search allocates nothing (hipGraph capture). */
+int ivr_index_reserve_search(ivr_index *idx, int max_nq, int max_k);
+/* Exact top-k by inner product.  q: DEV float32 [nq,d]; D: DEV float32 [nq,k] descending;
+ * I: DEV int64 [nq,k] = id_base + row, ties broken by lower id; unused slots (-FLT_MAX, -1). */
+int ivr_index_search(ivr_index *idx, const float *q /*DEV*/, int nq, int k, int normalize_q,
+                     int64_t id_base, float *D /*DEV*/, int64_t *I /*DEV*/, ivr_stream stream);
+/* Merge per-shard candidate lists (the reference's concat + sort of peer results, system.py:1744-1746):
+ * D_parts/I_parts DEV [parts, nq, k] with global ids, parts ordered by ascending id range. */
+int ivr_topk_merge(ivr_ctx *ctx, const float *D_parts /*DEV*/, const int64_t *I_parts /*DEV*/, int parts,
+                   int nq, int k, float *D /*DEV*/, int64_t *I /*DEV*/, ivr_stream stream);
+
+/* ---- D1: near-duplicate frame filter ------------------------------------------------------------
+ * Replaces the cosine_similarity(...) >= SIM_THRESHOLD loop at video_frame_filter.py:63-70.
+ * emb: DEV float32 [n,d] in frame order.  keep[t] = 1 iff cos(emb[t], last kept) < threshold.
+ * state: DEV float32 [d+1]: state[0] = 1 if a previous kept embedding is stored in state[1..d];
+ * updated in place so consecutive batches of one video continue the same sequence.
+ */
+int ivr_dedup_keep_mask(ivr_ctx *ctx, const float *emb /*DEV*/, int n, int d, float threshold,
+                        float *state /*DEV*/, uint8_t *keep /*DEV*/, ivr_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVR_API_H */

@@ -1,0 +1,80 @@
+// Internal helpers shared by the libivr_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "../../include/ivr_api.h"
+
+struct ivr_ctx {
+    int device = 0;
+    int cu_count = 256;
+    int64_t hbm_bytes = 0;
+    char arch[64] = {0};
+    std::mutex mu;
+    // grow-only device scratch (preprocess intermediates, merge workspaces)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::map<std::string, float *> luts;   // preprocess value tables, keyed by the mean/std bytes
+};
+
+std::string &ivr_err_slot();
+int ivr_fail(int code, const char *fmt, ...);
+
+#define IVR_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return ivr_fail(e__ == hipErrorOutOfMemory ? IVR_ERR_OOM : IVR_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                           \
+    } while (0)
+
+#define IVR_REQUIRE(cond, ...)                                     \
+    do {                                                           \
+        if (!(cond)) return ivr_fail(IVR_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define IVR_LAUNCH_CHECK() IVR_HIP(hipGetLastError())
+
+int ivr_ctx_scratch(ivr_ctx *ctx, size_t bytes, void **out);
+
+static inline int64_t ivr_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t ivr_round_up(int64_t a, int64_t b) { return ivr_ceil_div(a, b) * b; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+// float <-> order-preserving uint32 (larger float -> larger key); -0.0 is folded onto +0.0 first
+__device__ __forceinline__ uint32_t ivr_f2ord(float f) {
+    uint32_t u = __float_as_uint(f + 0.0f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ivr_ord2f(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+__device__ __forceinline__ float ivr_bf16_to_f32(unsigned short b) { return __uint_as_float(((uint32_t)b) << 16); }
+// round-to-nearest-even; NaN stays NaN
+__device__ __forceinline__ unsigned short ivr_f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+__device__ __forceinline__ float ivr_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float ivr_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,690 @@
+// Flat inner-product index on MI355X: tiled HBM layout, streaming scan with f32 MFMA,
+// exact top-k by group maxima + radix select.  (I1, N2/N3, S1 of SURVEY.md section 8a.)
+//
+// Replaces faiss.IndexFlatIP.add/search as called at unified_index.py:1767-1779,503 and
+// core.py:827,891.  Design:
+//
+//   layout   rows are stored in tiles of 16 rows; inside a tile the order is [d/4][16 rows][4 floats],
+//            so lane l of a wave reading float4 number l of a 1 KiB piece holds row (l & 15),
+//            floats 16*kc + 4*(l >> 4) .. +3: exactly the A fragment of v_mfma_f32_16x16x4_f32 for four
+//            consecutive MFMAs.  Every wave-wide load is 1 KiB contiguous.  Queries use the same layout
+//            (they are the B fragment), staged once per workgroup in LDS.
+//   pass 1   scan: each wave scores a group of 64 rows x (16*QT) queries, reduces the 64 scores of each
+//            query to their maximum (15 v_max + 2 wave shuffles) and stores it.  No data-dependent
+//            control flow, the index is read exactly once per 16*QT queries.
+//   pass 2   per query, radix-select the k groups with the largest (max, lowest group id).  The k best
+//            rows always lie inside those k groups (proof in DESIGN.md).
+//   pass 3   re-score the selected groups with the same MFMA sequence (bit-identical scores) and emit
+//            64-bit keys (ordered score, ~row).
+//   pass 4   per query, radix-select + bitonic sort of the k best keys -> D (float32), I (int64).
+#include "ivr_common.h"
+
+#include <algorithm>
+#include <cfloat>
+
+namespace {
+
+constexpr int kGroupRows = 64;      // rows per scan group (4 MFMA row tiles)
+constexpr int kSelThreads = 1024;   // select kernel block size
+constexpr int kMaxSort = IVR_MAX_K; // bitonic sort capacity (power of two)
+
+// ---------------------------------------------------------------------------------------------
+// tiling: row-major [n,d] -> tiled, with optional L2 normalisation (N2/N3) and non-finite count
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 load_quad(const float *__restrict__ row, int k0, int d, bool vec) {
+    if (vec) return *reinterpret_cast<const float4 *>(row + k0);   // k0 + 3 < d guaranteed by caller when vec
+    float4 v;
+    v.x = k0 + 0 < d ? row[k0 + 0] : 0.f;
+    v.y = k0 + 1 < d ? row[k0 + 1] : 0.f;
+    v.z = k0 + 2 < d ? row[k0 + 2] : 0.f;
+    v.w = k0 + 3 < d ? row[k0 + 3] : 0.f;
+    return v;
+}
+
+// one wave per 16-row tile; lane l owns row (l & 15) and quad (l >> 4) of every 16-float chunk
+__global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                        int64_t row_start, int64_t n, int d, int dp4,
+                                                        int normalize, int32_t *__restrict__ nonfinite) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile0 = row_start >> 4;
+    const int64_t ntiles = ((row_start + n + 15) >> 4) - tile0;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    const int64_t tile = tile0 + t;
+    const int rr = lane & 15, qd = lane >> 4;
+    const int64_t row = tile * 16 + rr;
+    const bool valid = row >= row_start && row < row_start + n;
+    const float *srow = src + (valid ? (row - row_start) : 0) * (int64_t)d;
+    const bool vec = (d & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    const int kchunks = dp4 >> 2;
+    float ss = 0.f;
+    int bad = 0;
+    if (normalize || nonfinite) {
+        for (int kc = 0; kc < kchunks; ++kc) {
+            const int k0 = kc * 16 + qd * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && k0 < d) v = load_quad(srow, k0, d, vec && k0 + 3 < d);
+            ss = fmaf(v.x, v.x, ss);
+            ss = fmaf(v.y, v.y, ss);
+            ss = fmaf(v.z, v.z, ss);
+            ss = fmaf(v.w, v.w, ss);
+            bad += !isfinite(v.x) + !isfinite(v.y) + !isfinite(v.z) + !isfinite(v.w);
+        }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (nonfinite) {
+            bad += __shfl_xor(bad, 16, 64);
+            bad += __shfl_xor(bad, 32, 64);
+            if (bad && qd == 0) atomicAdd(nonfinite, bad);
+        }
+    }
+    // core.py:1194-1196: norms[norms == 0] = 1; features / norms
+    const float nrm = normalize ? (ss > 0.f ? sqrtf(ss) : 1.f) : 1.f;
+    float4 *out = reinterpret_cast<float4 *>(dst) + tile * (int64_t)dp4 * 16 + lane;
+    for (int kc = 0; kc < kchunks; ++kc) {
+        const int k0 = kc * 16 + qd * 4;
+        if (valid) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 < d) v = load_quad(srow, k0, d, vec && k0 + 3 < d);
+            if (normalize) {
+                v.x /= nrm;
+                v.y /= nrm;
+                v.z /= nrm;
+                v.w /= nrm;
+            }
+            out[kc * 64] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void untile_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                          int64_t row_start, int64_t n, int d, int dp4) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile0 = row_start >> 4;
+    const int64_t ntiles = ((row_start + n + 15) >> 4) - tile0;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    const int64_t tile = tile0 + t;
+    const int rr = lane & 15, qd = lane >> 4;
+    const int64_t row = tile * 16 + rr;
+    if (row < row_start || row >= row_start + n) return;
+    const float4 *in = reinterpret_cast<const float4 *>(src) + tile * (int64_t)dp4 * 16 + lane;
+    float *drow = dst + (row - row_start) * (int64_t)d;
+    for (int kc = 0; kc < (dp4 >> 2); ++kc) {
+        const int k0 = kc * 16 + qd * 4;
+        const float4 v = in[kc * 64];
+        if (k0 + 0 < d) drow[k0 + 0] = v.x;
+        if (k0 + 1 < d) drow[k0 + 1] = v.y;
+        if (k0 + 2 < d) drow[k0 + 2] = v.z;
+        if (k0 + 3 < d) drow[k0 + 3] = v.w;
+    }
+}
+
+// in-place row normalisation of a row-major matrix (ivr_l2_normalize): one wave per row
+__global__ __launch_bounds__(256) void l2_normalize_kernel(float *__restrict__ x, int64_t n, int d,
+                                                           int32_t *__restrict__ nonfinite) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float *p = x + row * (int64_t)d;
+    float ss = 0.f;
+    int bad = 0;
+    for (int k = lane; k < d; k += 64) {
+        const float v = p[k];
+        ss = fmaf(v, v, ss);
+        bad += !isfinite(v);
+    }
+    ss = ivr_wave_sum(ss);
+    if (nonfinite) {
+        for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+        if (bad && lane == 0) atomicAdd(nonfinite, bad);
+    }
+    const float nrm = ss > 0.f ? sqrtf(ss) : 1.f;
+    for (int k = lane; k < d; k += 64) p[k] = p[k] / nrm;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the 64-row x 16-query score tile (shared by pass 1 and pass 3 so the scores are bit-identical)
+// ---------------------------------------------------------------------------------------------
+// a: this lane's float4 pointer into the group's first tile; tiles are tile_stride float4 apart.
+// acc[t][r] = <row 16t + 4(lane>>4) + r , query (lane&15)>
+template <int QT, typename BLoad>
+__device__ __forceinline__ void score_group(const float4 *__restrict__ a, int64_t tile_stride, int kchunks,
+                                            BLoad bload, f32x4 (&acc)[QT][4]) {
+#pragma unroll
+    for (int q = 0; q < QT; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // two 16-float chunks per trip: 8 independent 1 KiB loads in flight per wave before the MFMAs
+    int kc = 0;
+    for (; kc + 2 <= kchunks; kc += 2) {
+        float4 av[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[u][t] = a[t * tile_stride + (kc + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const float4 bv = bload(q, kc + u);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t].x, bv.x, acc[q][t], 0, 0, 0);
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t].y, bv.y, acc[q][t], 0, 0, 0);
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t].z, bv.z, acc[q][t], 0, 0, 0);
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t].w, bv.w, acc[q][t], 0, 0, 0);
+                }
+            }
+    }
+    if (kc < kchunks) {
+        float4 av[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) av[t] = a[t * tile_stride + kc * 64];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const float4 bv = bload(q, kc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].x, bv.x, acc[q][t], 0, 0, 0);
+                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].y, bv.y, acc[q][t], 0, 0, 0);
+                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].z, bv.z, acc[q][t], 0, 0, 0);
+                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv.w, acc[q][t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// pass 1.  gmax layout: [16*QT queries][mstride groups]
+template <int QT>
+__global__ __launch_bounds__(512) void scan_groupmax_kernel(const float *__restrict__ data,
+                                                            const float *__restrict__ qtiled, int dp4,
+                                                            int64_t ngroups, int64_t ntotal,
+                                                            float *__restrict__ gmax, int64_t mstride) {
+    extern __shared__ __attribute__((aligned(16))) float4 qs[];
+    const int per_tile = dp4 * 16;   // float4 per 16-row tile
+    for (int i = threadIdx.x; i < QT * per_tile; i += blockDim.x) qs[i] = reinterpret_cast<const float4 *>(qtiled)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int kchunks = dp4 >> 2;
+    auto bload = [&](int q, int kc) { return qs[q * per_tile + kc * 64 + lane]; };
+    for (int64_t g = (int64_t)blockIdx.x * nw + wave; g < ngroups; g += (int64_t)gridDim.x * nw) {
+        f32x4 acc[QT][4];
+        const float4 *a = reinterpret_cast<const float4 *>(data) + g * 4 * (int64_t)per_tile + lane;
+        score_group<QT>(a, per_tile, kchunks, bload, acc);
+        const bool partial = (g + 1) * kGroupRows > ntotal;   // wave-uniform: only the last group
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            float m = -FLT_MAX;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = acc[q][t][r];
+                    if (partial && g * kGroupRows + t * 16 + (lane >> 4) * 4 + r >= ntotal) s = -FLT_MAX;
+                    m = fmaxf(m, s);
+                }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            if (lane < 16) gmax[(int64_t)(q * 16 + lane) * mstride + g] = m;
+        }
+    }
+}
+
+// pass 3: one wave per (query, selected group).  cand[q][j*64 + row] = key(score, row id)
+__global__ __launch_bounds__(256) void rescore_groups_kernel(const float *__restrict__ data,
+                                                             const float *__restrict__ qtiled, int dp4,
+                                                             int64_t ntotal, const uint32_t *__restrict__ sel,
+                                                             int ksel, int nq, uint64_t *__restrict__ cand) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (int64_t)nq * ksel) return;
+    const int q = (int)(w / ksel), j = (int)(w % ksel);
+    const uint32_t g = sel[(int64_t)q * ksel + j];
+    uint64_t *out = cand + ((int64_t)q * ksel + j) * kGroupRows;
+    if (g == 0xFFFFFFFFu) {   // fewer groups than k
+        out[lane] = 0;
+        return;
+    }
+    const int per_tile = dp4 * 16;
+    const float4 *b = reinterpret_cast<const float4 *>(qtiled) + (int64_t)(q >> 4) * per_tile + lane;
+    auto bload = [&](int, int kc) { return b[kc * 64]; };
+    f32x4 acc[1][4];
+    const float4 *a = reinterpret_cast<const float4 *>(data) + (int64_t)g * 4 * per_tile + lane;
+    score_group<1>(a, per_tile, dp4 >> 2, bload, acc);
+    if ((lane & 15) == (q & 15)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = t * 16 + (lane >> 4) * 4 + r;
+                const int64_t row = (int64_t)g * kGroupRows + rl;
+                uint64_t key = 0;
+                if (row < ntotal) key = ((uint64_t)ivr_f2ord(acc[0][t][r]) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)row);
+                out[rl] = key;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-query exact top-k of 64-bit keys: MSB-first radix select (8 x 8 bits) + bitonic sort
+// ---------------------------------------------------------------------------------------------
+struct SrcGroupMax {   // pass 2: keys from the group-maximum column of query q
+    const float *gmax;
+    int64_t mstride;
+    int64_t n;
+    __device__ uint64_t key(int q, int64_t i) const {
+        return ((uint64_t)ivr_f2ord(gmax[(int64_t)q * mstride + i]) << 32) |
+               (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+    }
+};
+struct SrcKeys {       // pass 4: keys already materialised
+    const uint64_t *keys;
+    int64_t n;
+    __device__ uint64_t key(int q, int64_t i) const { return keys[(int64_t)q * n + i]; }
+};
+struct SrcParts {      // shard merge: candidate p = part*k + j; ties resolve to the lower p = lower global id
+    const float *D;
+    const int64_t *I;
+    int nq, k;
+    int64_t n;         // parts * k
+    __device__ uint64_t key(int q, int64_t p) const {
+        const int64_t part = p / k, j = p % k;
+        const int64_t off = (part * nq + q) * k + j;
+        if (I[off] < 0) return 0;
+        return ((uint64_t)ivr_f2ord(D[off]) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)p);
+    }
+};
+
+enum { OUT_GROUPS = 0, OUT_DI = 1, OUT_DI_PARTS = 2 };
+
+template <typename Src, int OUT>
+__global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int qcol0, int k, int64_t id_base,
+                                                                  uint32_t *__restrict__ out_groups,
+                                                                  float *__restrict__ D, int64_t *__restrict__ I,
+                                                                  const int64_t *__restrict__ I_parts) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix, s_mask;
+    __shared__ unsigned int s_kth, s_cnt, s_valid;
+    __shared__ uint64_t sorted[kMaxSort];
+    const int q = blockIdx.x;
+    const int qsrc = qcol0 + q;
+    const int tid = threadIdx.x;
+    const int64_t n = src.n;
+
+    // count valid keys (key 0 = absent)
+    if (tid == 0) s_valid = 0;
+    __syncthreads();
+    {
+        unsigned int c = 0;
+        for (int64_t i = tid; i < n; i += kSelThreads) c += src.key(qsrc, i) != 0;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((tid & 63) == 0 && c) atomicAdd(&s_valid, c);
+    }
+    __syncthreads();
+    const unsigned int keff = min((unsigned int)k, s_valid);
+    uint64_t tau = ~0ull;   // nothing selected when keff == 0
+    if (keff > 0) {
+        if (tid == 0) {
+            s_prefix = 0;
+            s_mask = 0;
+            s_kth = keff;
+        }
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix, mask = s_mask;
+            for (int64_t i = tid; i < n; i += kSelThreads) {
+                const uint64_t key = src.key(qsrc, i);
+                if (key != 0 && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned int kth = s_kth, cum = 0;
+                int dsel = 0;
+                for (int dgt = 255; dgt >= 0; --dgt) {
+                    const unsigned int h = hist[dgt];
+                    if (cum + h >= kth) {
+                        dsel = dgt;
+                        break;
+                    }
+                    cum += h;
+                }
+                s_kth = kth - cum;
+                s_prefix = prefix | ((unsigned long long)dsel << shift);
+                s_mask = mask | (0xFFull << shift);
+            }
+            __syncthreads();
+        }
+        tau = s_prefix;   // the keff-th largest key (keys are unique)
+    }
+    // gather keys >= tau, pad, sort descending
+    int P = 1;
+    while (P < (int)keff) P <<= 1;
+    if (tid == 0) s_cnt = 0;
+    for (int i = tid; i < P; i += kSelThreads) sorted[i] = 0;
+    __syncthreads();
+    if (keff > 0) {
+        for (int64_t i = tid; i < n; i += kSelThreads) {
+            const uint64_t key = src.key(qsrc, i);
+            if (key != 0 && key >= tau) {
+                const unsigned int slot = atomicAdd(&s_cnt, 1u);
+                if (slot < (unsigned int)kMaxSort) sorted[slot] = key;
+            }
+        }
+    }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (P >> 1); i += kSelThreads) {
+                const int lo = ((i / stride) * stride * 2) + (i % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const uint64_t a = sorted[lo], b = sorted[hi];
+                if ((a < b) == desc) {
+                    sorted[lo] = b;
+                    sorted[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < k; j += kSelThreads) {
+        const uint64_t key = j < (int)keff ? sorted[j] : 0;
+        const uint32_t low = 0xFFFFFFFFu - (uint32_t)key;
+        if (OUT == OUT_GROUPS) {
+            out_groups[(int64_t)q * k + j] = key ? low : 0xFFFFFFFFu;
+        } else {
+            D[(int64_t)q * k + j] = key ? ivr_ord2f((uint32_t)(key >> 32)) : -FLT_MAX;
+            int64_t id = -1;
+            if (key) {
+                if (OUT == OUT_DI_PARTS) {
+                    const int kk = ((const SrcParts *)&src)->k, nq = ((const SrcParts *)&src)->nq;
+                    id = I_parts[((int64_t)(low / kk) * nq + q) * kk + (low % kk)];
+                } else {
+                    id = id_base + (int64_t)low;
+                }
+            }
+            I[(int64_t)q * k + j] = id;
+        }
+    }
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+struct ivr_index {
+    ivr_ctx *ctx = nullptr;
+    int d = 0, dp = 0, dp4 = 0;
+    int64_t cap = 0, ntotal = 0;     // cap is a multiple of kGroupRows
+    float *data = nullptr;
+    std::mutex mu;
+    // search workspace (grow-only)
+    float *qtiled = nullptr;         // [qtiles][dp4][16][4]
+    int qtiles_cap = 0;
+    float *gmax = nullptr;           // [qcols][mstride]
+    int64_t gmax_floats = 0;
+    uint32_t *sel = nullptr;         // [nq][ksel]
+    uint64_t *cand = nullptr;        // [nq][ksel*64]
+    int64_t sel_cap = 0;             // in (nq*ksel) units
+};
+
+namespace {
+
+int64_t tile_bytes(const ivr_index *x, int64_t rows) { return rows * (int64_t)x->dp * 4; }
+
+int index_alloc(ivr_index *x, int64_t rows) {
+    rows = ivr_round_up(std::max<int64_t>(rows, kGroupRows), kGroupRows);
+    float *nd = nullptr;
+    IVR_HIP(hipMalloc(&nd, (size_t)tile_bytes(x, rows)));
+    IVR_HIP(hipMemset(nd, 0, (size_t)tile_bytes(x, rows)));
+    if (x->data) {
+        if (x->ntotal > 0)
+            IVR_HIP(hipMemcpy(nd, x->data, (size_t)tile_bytes(x, ivr_round_up(x->ntotal, 16)), hipMemcpyDeviceToDevice));
+        IVR_HIP(hipFree(x->data));
+    }
+    x->data = nd;
+    x->cap = rows;
+    return IVR_OK;
+}
+
+int launch_tile_rows(ivr_index *x, float *dst, const float *src, int64_t start, int64_t n, int normalize,
+                     int32_t *nonfinite, hipStream_t s) {
+    if (n <= 0) return IVR_OK;
+    const int64_t ntiles = ((start + n + 15) >> 4) - (start >> 4);
+    const unsigned grid = (unsigned)ivr_ceil_div(ntiles, 4);
+    hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, src, dst, start, n, x->d, x->dp4, normalize, nonfinite);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+// choose the query tile width of the scan (queries per index pass = 16*QT)
+int pick_qt(int nq) { return nq <= 16 ? 1 : nq <= 32 ? 2 : nq <= 48 ? 3 : 4; }
+
+int reserve_search(ivr_index *x, int nq, int k) {
+    const int qtiles = (int)ivr_ceil_div(nq, 16);
+    if (qtiles > x->qtiles_cap) {
+        if (x->qtiles_cap) IVR_HIP(hipFree(x->qtiled));
+        x->qtiled = nullptr;
+        x->qtiles_cap = 0;
+        const int want = std::max(qtiles, 4);
+        IVR_HIP(hipMalloc(&x->qtiled, (size_t)want * 16 * x->dp * 4));
+        IVR_HIP(hipMemset(x->qtiled, 0, (size_t)want * 16 * x->dp * 4));
+        x->qtiles_cap = want;
+    }
+    const int64_t mstride = ivr_round_up(x->cap / kGroupRows, 64);
+    const int64_t need_gmax = (int64_t)64 * mstride;   // one scan chunk = up to 64 query columns
+    if (need_gmax > x->gmax_floats) {
+        if (x->gmax) IVR_HIP(hipFree(x->gmax));
+        x->gmax = nullptr;
+        x->gmax_floats = 0;
+        IVR_HIP(hipMalloc(&x->gmax, (size_t)need_gmax * 4));
+        x->gmax_floats = need_gmax;
+    }
+    const int64_t need_sel = (int64_t)std::min(nq, 64) * k;   // per scan chunk
+    if (need_sel > x->sel_cap) {
+        if (x->sel) IVR_HIP(hipFree(x->sel));
+        if (x->cand) IVR_HIP(hipFree(x->cand));
+        x->sel = nullptr;
+        x->cand = nullptr;
+        x->sel_cap = 0;
+        IVR_HIP(hipMalloc(&x->sel, (size_t)need_sel * 4));
+        IVR_HIP(hipMalloc(&x->cand, (size_t)need_sel * kGroupRows * 8));
+        x->sel_cap = need_sel;
+    }
+    return IVR_OK;
+}
+
+template <int QT>
+void launch_scan(ivr_index *x, const float *qt, int64_t ngroups, int64_t mstride, hipStream_t s) {
+    const size_t lds = (size_t)QT * 16 * x->dp * 4;
+    // 8 waves per workgroup share one staged query tile; size the grid so every CU holds as many
+    // workgroups as the LDS allows and let each wave stride over the groups
+    const int threads = 512, nw = threads / 64;
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds, 1)));
+    int64_t grid = std::min<int64_t>(ivr_ceil_div(ngroups, nw), (int64_t)x->ctx->cu_count * per_cu);
+    grid = std::max<int64_t>(grid, 1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scan_groupmax_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    hipLaunchKernelGGL(scan_groupmax_kernel<QT>, dim3((unsigned)grid), dim3(threads), lds, s, x->data, qt, x->dp4, ngroups,
+                       x->ntotal, x->gmax, mstride);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ivr_index_create(ivr_ctx *ctx, int d, int64_t capacity_rows, ivr_index **out) {
+    IVR_REQUIRE(ctx && out, "ivr_index_create: NULL argument");
+    IVR_REQUIRE(d >= 1 && d <= 2048, "ivr_index_create: d=%d out of range [1,2048]", d);
+    IVR_REQUIRE(capacity_rows >= 0 && capacity_rows < (1ll << 32) - 64, "ivr_index_create: capacity %lld out of range",
+                (long long)capacity_rows);
+    IVR_HIP(hipSetDevice(ctx->device));
+    ivr_index *x = new ivr_index();
+    x->ctx = ctx;
+    x->d = d;
+    x->dp = (int)ivr_round_up(d, 16);
+    x->dp4 = x->dp / 4;
+    int rc = index_alloc(x, capacity_rows);
+    if (rc != IVR_OK) {
+        delete x;
+        return rc;
+    }
+    *out = x;
+    return IVR_OK;
+}
+
+int ivr_index_destroy(ivr_index *x) {
+    if (!x) return IVR_OK;
+    if (x->data) (void)hipFree(x->data);
+    if (x->qtiled) (void)hipFree(x->qtiled);
+    if (x->gmax) (void)hipFree(x->gmax);
+    if (x->sel) (void)hipFree(x->sel);
+    if (x->cand) (void)hipFree(x->cand);
+    delete x;
+    return IVR_OK;
+}
+
+int ivr_index_reset(ivr_index *x) {
+    IVR_REQUIRE(x, "ivr_index_reset: NULL index");
+    std::lock_guard<std::mutex> lk(x->mu);
+    IVR_HIP(hipSetDevice(x->ctx->device));
+    IVR_HIP(hipMemset(x->data, 0, (size_t)tile_bytes(x, x->cap)));
+    x->ntotal = 0;
+    return IVR_OK;
+}
+
+int64_t ivr_index_ntotal(ivr_index *x) { return x ? x->ntotal : 0; }
+int ivr_index_dim(ivr_index *x) { return x ? x->d : 0; }
+int64_t ivr_index_capacity(ivr_index *x) { return x ? x->cap : 0; }
+
+int ivr_index_add(ivr_index *x, const float *rows, int64_t n, int normalize, ivr_stream stream) {
+    IVR_REQUIRE(x && (rows || n == 0), "ivr_index_add: NULL argument");
+    IVR_REQUIRE(n >= 0, "ivr_index_add: n=%lld", (long long)n);
+    std::lock_guard<std::mutex> lk(x->mu);
+    IVR_HIP(hipSetDevice(x->ctx->device));
+    if (x->ntotal + n > x->cap) {
+        IVR_REQUIRE(x->ntotal + n < (1ll << 32) - 64, "ivr_index_add: index would exceed 2^32 rows");
+        // growing re-allocates: wait for work that may still read the old buffer
+        IVR_HIP(hipDeviceSynchronize());
+        int rc = index_alloc(x, std::max<int64_t>(x->ntotal + n, x->cap + x->cap / 2));
+        if (rc != IVR_OK) return rc;
+    }
+    int rc = launch_tile_rows(x, x->data, rows, x->ntotal, n, normalize, nullptr, (hipStream_t)stream);
+    if (rc != IVR_OK) return rc;
+    x->ntotal += n;
+    return IVR_OK;
+}
+
+int ivr_index_write(ivr_index *x, int64_t start, const float *rows, int64_t n, int normalize, ivr_stream stream) {
+    IVR_REQUIRE(x && (rows || n == 0), "ivr_index_write: NULL argument");
+    std::lock_guard<std::mutex> lk(x->mu);
+    IVR_REQUIRE(start >= 0 && n >= 0 && start + n <= x->ntotal, "ivr_index_write: rows [%lld,%lld) outside [0,%lld)",
+                (long long)start, (long long)(start + n), (long long)x->ntotal);
+    IVR_HIP(hipSetDevice(x->ctx->device));
+    return launch_tile_rows(x, x->data, rows, start, n, normalize, nullptr, (hipStream_t)stream);
+}
+
+int ivr_index_reconstruct(ivr_index *x, int64_t start, int64_t n, float *out, ivr_stream stream) {
+    IVR_REQUIRE(x && (out || n == 0), "ivr_index_reconstruct: NULL argument");
+    std::lock_guard<std::mutex> lk(x->mu);
+    IVR_REQUIRE(start >= 0 && n >= 0 && start + n <= x->ntotal, "ivr_index_reconstruct: rows [%lld,%lld) outside [0,%lld)",
+                (long long)start, (long long)(start + n), (long long)x->ntotal);
+    if (n == 0) return IVR_OK;
+    IVR_HIP(hipSetDevice(x->ctx->device));
+    const int64_t ntiles = ((start + n + 15) >> 4) - (start >> 4);
+    hipLaunchKernelGGL(untile_rows_kernel, dim3((unsigned)ivr_ceil_div(ntiles, 4)), dim3(256), 0, (hipStream_t)stream, x->data,
+                       out, start, n, x->d, x->dp4);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+int ivr_index_reserve_search(ivr_index *x, int max_nq, int max_k) {
+    IVR_REQUIRE(x, "ivr_index_reserve_search: NULL index");
+    IVR_REQUIRE(max_nq >= 1 && max_k >= 1 && max_k <= IVR_MAX_K, "ivr_index_reserve_search: nq=%d k=%d", max_nq, max_k);
+    std::lock_guard<std::mutex> lk(x->mu);
+    IVR_HIP(hipSetDevice(x->ctx->device));
+    return reserve_search(x, max_nq, max_k);
+}
+
+int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_q, int64_t id_base, float *D, int64_t *I,
+                     ivr_stream stream) {
+    IVR_REQUIRE(x && q && D && I, "ivr_index_search: NULL argument");
+    IVR_REQUIRE(nq >= 1, "ivr_index_search: nq=%d", nq);
+    IVR_REQUIRE(k >= 1 && k <= IVR_MAX_K, "ivr_index_search: k=%d outside [1,%d]", k, IVR_MAX_K);
+    std::lock_guard<std::mutex> lk(x->mu);
+    IVR_HIP(hipSetDevice(x->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = reserve_search(x, nq, k);
+    if (rc != IVR_OK) return rc;
+    const int64_t ngroups = ivr_ceil_div(x->ntotal, kGroupRows);
+    const int64_t mstride = ivr_round_up(x->cap / kGroupRows, 64);
+    // queries -> tiled layout (normalised on the way when asked: N2 on the query side, core.py:875)
+    {
+        const int64_t ntiles = ivr_ceil_div(nq, 16);
+        IVR_HIP(hipMemsetAsync(x->qtiled, 0, (size_t)ntiles * 16 * x->dp * 4, s));
+        rc = launch_tile_rows(x, x->qtiled, q, 0, nq, normalize_q, nullptr, s);
+        if (rc != IVR_OK) return rc;
+    }
+    const int ksel = k;
+    // queries per index pass: as many 16-query tiles as fit 128 KiB of LDS, at most 4
+    const int qt_max = (int)std::max<int64_t>(1, std::min<int64_t>(4, (128 * 1024) / ((int64_t)16 * x->dp * 4)));
+    const int chunk = 16 * qt_max;
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nqc = std::min(chunk, nq - q0);
+        const int qt = pick_qt(nqc);
+        const float *qtile = x->qtiled + (int64_t)(q0 / 16) * 16 * x->dp;
+        if (ngroups > 0) {
+            switch (qt) {
+                case 1: launch_scan<1>(x, qtile, ngroups, mstride, s); break;
+                case 2: launch_scan<2>(x, qtile, ngroups, mstride, s); break;
+                case 3: launch_scan<3>(x, qtile, ngroups, mstride, s); break;
+                default: launch_scan<4>(x, qtile, ngroups, mstride, s); break;
+            }
+            IVR_LAUNCH_CHECK();
+        }
+        SrcGroupMax sg{x->gmax, mstride, ngroups};
+        hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(kSelThreads), 0, s, sg, 0, ksel,
+                           (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr);
+        IVR_LAUNCH_CHECK();
+        const int64_t waves = (int64_t)nqc * ksel;
+        // rescore reads query tile (q >> 4) relative to the chunk's first tile
+        hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)ivr_ceil_div(waves, 4)), dim3(256), 0, s, x->data, qtile,
+                           x->dp4, x->ntotal, x->sel, ksel, nqc, x->cand);
+        IVR_LAUNCH_CHECK();
+        SrcKeys sk{x->cand, (int64_t)ksel * kGroupRows};
+        hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(kSelThreads), 0, s, sk, 0, k, id_base,
+                           (uint32_t *)nullptr, D + (int64_t)q0 * k, I + (int64_t)q0 * k, (const int64_t *)nullptr);
+        IVR_LAUNCH_CHECK();
+    }
+    return IVR_OK;
+}
+
+int ivr_topk_merge(ivr_ctx *ctx, const float *D_parts, const int64_t *I_parts, int parts, int nq, int k, float *D,
+                   int64_t *I, ivr_stream stream) {
+    IVR_REQUIRE(ctx && D_parts && I_parts && D && I, "ivr_topk_merge: NULL argument");
+    IVR_REQUIRE(parts >= 1 && nq >= 1 && k >= 1 && k <= IVR_MAX_K, "ivr_topk_merge: parts=%d nq=%d k=%d", parts, nq, k);
+    IVR_HIP(hipSetDevice(ctx->device));
+    SrcParts sp{D_parts, I_parts, nq, k, (int64_t)parts * k};
+    hipLaunchKernelGGL((select_topk_kernel<SrcParts, OUT_DI_PARTS>), dim3(nq), dim3(kSelThreads), 0, (hipStream_t)stream, sp, 0,
+                       k, (int64_t)0, (uint32_t *)nullptr, D, I, I_parts);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+int ivr_l2_normalize(ivr_ctx *ctx, float *x, int64_t n, int d, int32_t *nonfinite, ivr_stream stream) {
+    IVR_REQUIRE(ctx && (x || n == 0), "ivr_l2_normalize: NULL argument");
+    IVR_REQUIRE(n >= 0 && d >= 1, "ivr_l2_normalize: n=%lld d=%d", (long long)n, d);
+    if (n == 0) return IVR_OK;
+    IVR_HIP(hipSetDevice(ctx->device));
+    if (nonfinite) IVR_HIP(hipMemsetAsync(nonfinite, 0, 4, (hipStream_t)stream));
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3((unsigned)ivr_ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, x, n, d,
+                       nonfinite);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+}  // extern "C"

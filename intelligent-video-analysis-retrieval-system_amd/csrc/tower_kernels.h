@@ -1,0 +1,30 @@
+// Launchers implemented in tower_kernels.hip.
+#pragma once
+#include "ivr_common.h"
+
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_PATCH = 2, EPI_F32 = 3 };
+
+struct GemmArgs {
+    const void *A = nullptr;   // X [M,K] row-major, compute dtype
+    int lda = 0;
+    const void *W = nullptr;   // W [N,K] row-major (nn.Linear), compute dtype
+    int ldw = 0;
+    int M = 0, N = 0, K = 0;
+    const float *bias = nullptr;   // [N] or NULL
+    void *out = nullptr;           // EPI_STORE: compute dtype [M,ldo]; EPI_F32: float [M,ldo]
+    int ldo = 0;
+    float *resid = nullptr;        // EPI_RESID: += in place; EPI_PATCH: token rows written
+    int ldr = 0;
+    const float *pos = nullptr;    // EPI_PATCH: position embedding [T,N]
+    int T = 0, G2 = 0;             // tokens per image, patches per image
+    int act = -1;                  // EPI_STORE: -1 none, else IVR_ACT_*
+};
+
+int ivr_launch_gemm(bool f32, int epi, const GemmArgs &g, hipStream_t s);
+int ivr_launch_layernorm(bool out_f32, const float *x, int row_mul, const int *offs, const float *g, const float *b, float eps,
+                         void *out, int rows, int D, hipStream_t s);
+int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int D, int heads, int causal, hipStream_t s);
+int ivr_launch_vision_cls(float *resid, const float *cls, const float *pos, int n, int T, int D, hipStream_t s);
+int ivr_launch_text_embed(float *resid, const int64_t *ids, const float *tok, const float *pos, int q, int T, int D, int vocab,
+                          int eos, int *eos_pos, hipStream_t s);
+int ivr_launch_f_normalize(const float *x, float *out, int n, int d, int normalize, hipStream_t s);

@@ -1,0 +1,503 @@
+// Kernels of the encoder towers (E1/E2/E3 + N1 of SURVEY.md section 8a), gfx950 only.
+//
+// The arithmetic follows what the reference obtains from HuggingFace at core.py:1619-1620,
+// core.py:1541-1542 and video_frame_filter.py:31-32 (modeling_clip.py:138-218, 259-383, 594-656,
+// 719-753, 541-581; modeling_vit.py:261-281, 348, 385):
+//   residual stream, LayerNorm statistics, softmax and every accumulation in float32;
+//   GEMM operands bf16 on v_mfma_f32_16x16x32_bf16 (IVR_COMPUTE_BF16) or float32 on
+//   v_mfma_f32_16x16x4_f32 (IVR_COMPUTE_F32, verification mode).
+//
+// GEMM: C[m][n] = sum_k X[m][k] * W[n][k]  (nn.Linear: both operands K-contiguous).
+//   128 x 128 x 128-byte tile, 4 waves as 2(m) x 2(n), each wave 64 x 64 = 4 x 4 MFMA tiles.
+//   The MFMA is issued with W as the A operand and X as the B operand, so a lane ends up holding
+//   4 consecutive n of one row m: bias/activation/residual epilogues are float4-wide and the
+//   residual stream is updated in place.
+//   Staging is register-split (issue the next tile's 16-byte full-line loads, compute the current
+//   tile from LDS, then write the registers to the other LDS buffer; one barrier per K step).
+//   LDS rows are 128 bytes; 16-byte chunk c of row r sits at chunk (c ^ (r & 7)), which makes both the
+//   ds_write_b128 of whole rows and the ds_read_b128 of MFMA fragments bank-conflict free.
+//   Workgroup ids are remapped so that the tiles sharing an X row panel run on one XCD (one L2).
+#include "tower.h"
+#include "tower_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// element helpers: T = unsigned short (bf16 bits) or float
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct El;
+template <>
+struct El<unsigned short> {
+    static constexpr int per16 = 8;   // elements per 16 bytes
+    static __device__ __forceinline__ void unpack(const uint4 &u, float (&f)[8]) {
+        f[0] = __uint_as_float(u.x << 16);
+        f[1] = __uint_as_float(u.x & 0xffff0000u);
+        f[2] = __uint_as_float(u.y << 16);
+        f[3] = __uint_as_float(u.y & 0xffff0000u);
+        f[4] = __uint_as_float(u.z << 16);
+        f[5] = __uint_as_float(u.z & 0xffff0000u);
+        f[6] = __uint_as_float(u.w << 16);
+        f[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void store4(unsigned short *p, const float (&v)[4]) {
+        uint2 o;
+        o.x = ivr_f32_to_bf16(v[0]) | ((uint32_t)ivr_f32_to_bf16(v[1]) << 16);
+        o.y = ivr_f32_to_bf16(v[2]) | ((uint32_t)ivr_f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2 *>(p) = o;
+    }
+};
+template <>
+struct El<float> {
+    static constexpr int per16 = 4;
+    static __device__ __forceinline__ void store4(float *p, const float (&v)[4]) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+
+__device__ __forceinline__ float act_fn(float x, int act) {
+    if (act == IVR_ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));   // x * sigmoid(1.702 x)
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// embeddings
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vision_cls_kernel(float *__restrict__ resid, const float *__restrict__ cls,
+                                                         const float *__restrict__ pos, int T, int D) {
+    float *row = resid + (int64_t)blockIdx.x * T * D;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) row[k] = cls[k] + pos[k];
+}
+
+__global__ __launch_bounds__(256) void text_embed_kernel(float *__restrict__ resid, const int64_t *__restrict__ ids,
+                                                         const float *__restrict__ tok, const float *__restrict__ pos,
+                                                         int T, int D, int vocab) {
+    const int64_t r = blockIdx.x;          // q*T + t
+    const int t = (int)(r % T);
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float *e = tok + id * D;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) resid[r * D + k] = e[k] + pos[(int64_t)t * D + k];
+}
+
+// first position of eos_id in each row, 0 when absent (modeling_clip.py:566-576: (ids == eos).int().argmax(-1))
+__global__ void eos_pos_kernel(const int64_t *__restrict__ ids, int q, int T, int eos, int *__restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= q) return;
+    int p = 0;
+    for (int t = 0; t < T; ++t)
+        if (ids[(int64_t)r * T + t] == eos) {
+            p = t;
+            break;
+        }
+    out[r] = p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers, two-pass statistics in float32
+// source row of output row r: r * row_mul + (offs ? offs[r] : 0)
+// ---------------------------------------------------------------------------------------------
+template <typename TOut>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int row_mul, const int *__restrict__ offs,
+                                                        const float *__restrict__ g, const float *__restrict__ b, float eps,
+                                                        TOut *__restrict__ out, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t srow = (int64_t)row * row_mul + (offs ? offs[row] : 0);
+    const float4 *src = reinterpret_cast<const float4 *>(x + srow * D);
+    const int nv = D >> 2;
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < nv) {
+            v[i] = src[idx];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = ivr_wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            ss += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(ivr_wave_sum(ss) / (float)D + eps);
+    TOut *orow = out + (int64_t)row * D;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 gg = reinterpret_cast<const float4 *>(g)[idx], bv = reinterpret_cast<const float4 *>(b)[idx];
+            float y[4];
+            y[0] = (v[i].x - mean) * rstd * gg.x + bv.x;
+            y[1] = (v[i].y - mean) * rstd * gg.y + bv.y;
+            y[2] = (v[i].z - mean) * rstd * gg.z + bv.z;
+            y[3] = (v[i].w - mean) * rstd * gg.w + bv.w;
+            El<TOut>::store4(orow + idx * 4, y);
+        }
+    }
+}
+
+// F.normalize(x, p=2, dim=1): x / max(||x||, 1e-12)  (core.py:1620)
+__global__ __launch_bounds__(256) void f_normalize_kernel(const float *__restrict__ x, float *__restrict__ out, int n, int d,
+                                                          int normalize) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *p = x + (int64_t)row * d;
+    float ss = 0.f;
+    for (int k = lane; k < d; k += 64) ss = fmaf(p[k], p[k], ss);
+    ss = ivr_wave_sum(ss);
+    const float den = normalize ? fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+    for (int k = lane; k < d; k += 64) out[(int64_t)row * d + k] = p[k] / den;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM
+// ---------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, ROWB = 128;            // ROWB: bytes of K per LDS row and K step
+constexpr int TILE_BYTES = BM * ROWB;                     // 16 KiB per operand per stage
+constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;              // 64 KiB
+
+template <typename T>
+__device__ __forceinline__ void mma_chunk(const uint4 &w, const uint4 &x, f32x4 &acc);
+template <>
+__device__ __forceinline__ void mma_chunk<unsigned short>(const uint4 &w, const uint4 &x, f32x4 &acc) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<float>(const uint4 &w, const uint4 &x, f32x4 &acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+    // bijective XCD remap: workgroups b, b+8, b+16, ... share an XCD; give each XCD a contiguous id range
+    const int nwg = MT * NT;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = bid / NT, tn = bid % NT;
+    const int m0 = tm * BM, n0 = tn * BN;
+    constexpr int EPR = ROWB / (int)sizeof(T);   // elements of K per step
+    const int KT = g.K / EPR;
+
+    // staging assignment: 16 slots of 8 rows per operand; wave w owns slots 4w..4w+3
+    const unsigned char *srcX[4], *srcW[4];
+    int dst[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (wave * 4 + j) + (lane >> 3), c = lane & 7;
+        const int xm = min(m0 + r, g.M - 1), wr = min(n0 + r, g.N - 1);
+        srcX[j] = reinterpret_cast<const unsigned char *>(g.A) + ((int64_t)xm * g.lda) * sizeof(T) + c * 16;
+        srcW[j] = reinterpret_cast<const unsigned char *>(g.W) + ((int64_t)wr * g.ldw) * sizeof(T) + c * 16;
+        dst[j] = r * ROWB + ((c ^ (r & 7)) << 4);
+    }
+    // fragment read offsets inside a 16-row tile for the two 64-byte halves of a row
+    int foff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) foff[kk] = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    f32x4 acc[4][4];   // [nt][mt]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 rx[4], rw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        rx[j] = *reinterpret_cast<const uint4 *>(srcX[j]);
+        rw[j] = *reinterpret_cast<const uint4 *>(srcW[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<uint4 *>(smem + dst[j]) = rx[j];
+        *reinterpret_cast<uint4 *>(smem + TILE_BYTES + dst[j]) = rw[j];
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        unsigned char *cur = smem + (kt & 1) * 2 * TILE_BYTES;
+        unsigned char *nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+        const bool more = kt + 1 < KT;
+        if (more) {
+            const int64_t adv = (int64_t)(kt + 1) * ROWB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rx[j] = *reinterpret_cast<const uint4 *>(srcX[j] + adv);
+                rw[j] = *reinterpret_cast<const uint4 *>(srcW[j] + adv);
+            }
+        }
+        const unsigned char *xs = cur + (wm * 64) * ROWB, *ws = cur + TILE_BYTES + (wn * 64) * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 xf[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xf[t] = *reinterpret_cast<const uint4 *>(xs + t * 16 * ROWB + foff[kk]);
+                wf[t] = *reinterpret_cast<const uint4 *>(ws + t * 16 * ROWB + foff[kk]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(wf[nt], xf[mt], acc[nt][mt]);
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<uint4 *>(nxt + dst[j]) = rx[j];
+                *reinterpret_cast<uint4 *>(nxt + TILE_BYTES + dst[j]) = rw[j];
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds C[m][n..n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+            if (n >= g.N) continue;
+            float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+            if (g.bias) {
+                const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n);
+                v[0] += bv.x;
+                v[1] += bv.y;
+                v[2] += bv.z;
+                v[3] += bv.w;
+            }
+            if (EPI == EPI_STORE) {
+                if (g.act >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = act_fn(v[i], g.act);
+                }
+                El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)m * g.ldo + n, v);
+            } else if (EPI == EPI_RESID) {
+                float4 *p = reinterpret_cast<float4 *>(g.resid + (int64_t)m * g.ldr + n);
+                float4 r = *p;
+                r.x += v[0];
+                r.y += v[1];
+                r.z += v[2];
+                r.w += v[3];
+                *p = r;
+            } else if (EPI == EPI_PATCH) {
+                const int img = m / g.G2, pch = m % g.G2;
+                const float4 pv = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + n);
+                float4 r = make_float4(v[0] + pv.x, v[1] + pv.y, v[2] + pv.z, v[3] + pv.w);
+                *reinterpret_cast<float4 *>(g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr + n) = r;
+            } else {   // EPI_F32
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)m * g.ldo + n) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention for short sequences (T = 50 / 77 / 197 / 257, head_dim 64): one workgroup per
+// (head, image); K and V of the head staged in LDS, one query row per lane, float32 online softmax.
+// The 1/sqrt(64) scale is folded into the Q weights at upload (exact: a power of two).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load_row64(const T *p, float (&f)[64]);
+template <>
+__device__ __forceinline__ void load_row64<unsigned short>(const unsigned short *p, float (&f)[64]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float t[8];
+        El<unsigned short>::unpack(reinterpret_cast<const uint4 *>(p)[c], t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[c * 8 + i] = t[i];
+    }
+}
+template <>
+__device__ __forceinline__ void load_row64<float>(const float *p, float (&f)[64]) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float4 v = reinterpret_cast<const float4 *>(p)[c];
+        f[c * 4 + 0] = v.x;
+        f[c * 4 + 1] = v.y;
+        f[c * 4 + 2] = v.z;
+        f[c * 4 + 3] = v.w;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void attention_kernel(const T *__restrict__ qkv, T *__restrict__ att, int Tn, int D, int causal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *Ks = reinterpret_cast<T *>(smem);
+    T *Vs = Ks + (size_t)Tn * 64;
+    const int h = blockIdx.x, img = blockIdx.y;
+    const int64_t base = (int64_t)img * Tn * 3 * D + h * 64;
+    constexpr int C16 = 64 / El<T>::per16;   // 16-byte chunks per 64-element row
+    for (int i = threadIdx.x; i < Tn * C16; i += blockDim.x) {
+        const int t = i / C16, c = i % C16;
+        const uint4 *kp = reinterpret_cast<const uint4 *>(qkv + base + (int64_t)t * 3 * D + D) + c;
+        const uint4 *vp = reinterpret_cast<const uint4 *>(qkv + base + (int64_t)t * 3 * D + 2 * D) + c;
+        reinterpret_cast<uint4 *>(Ks)[i] = *kp;
+        reinterpret_cast<uint4 *>(Vs)[i] = *vp;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    const bool active = t < Tn;
+    float q[64], o[64];
+    if (active) load_row64<T>(qkv + base + (int64_t)t * 3 * D, q);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        o[i] = 0.f;
+        if (!active) q[i] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    // wave-uniform key bound: all keys, or (last query of this wave) + 1 under the causal mask
+    int jmax = Tn;
+    if (causal) jmax = min(Tn, (int)((threadIdx.x | 63) + 1));
+    for (int j = 0; j < jmax; ++j) {
+        float kv[64];
+        load_row64<T>(Ks + (size_t)j * 64, kv);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; i += 4) {
+            s0 = fmaf(q[i], kv[i], s0);
+            s1 = fmaf(q[i + 1], kv[i + 1], s1);
+            s2 = fmaf(q[i + 2], kv[i + 2], s2);
+            s3 = fmaf(q[i + 3], kv[i + 3], s3);
+        }
+        float s = (s0 + s1) + (s2 + s3);
+        if (causal && j > t) s = -INFINITY;
+        if (__any(s > m)) {
+            const float mn = fmaxf(m, s);
+            const float alpha = (m == -INFINITY) ? 0.f : __expf(m - mn);
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) o[i] *= alpha;
+        }
+        const float p = (s == -INFINITY) ? 0.f : __expf(s - m);
+        l += p;
+        load_row64<T>(Vs + (size_t)j * 64, kv);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) o[i] = fmaf(p, kv[i], o[i]);
+    }
+    if (active) {
+        const float inv = 1.0f / l;
+        T *op = att + ((int64_t)img * Tn + t) * D + h * 64;
+#pragma unroll
+        for (int i = 0; i < 64; i += 4) {
+            const float v[4] = {o[i] * inv, o[i + 1] * inv, o[i + 2] * inv, o[i + 3] * inv};
+            El<T>::store4(op + i, v);
+        }
+    }
+}
+
+template <typename T, int EPI>
+int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
+    const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    GEMM_LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, EPI>), dim3(MT * NT), dim3(256), GEMM_LDS, s, g);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+template <typename T>
+int launch_gemm_e(int epi, const GemmArgs &g, hipStream_t s) {
+    switch (epi) {
+        case EPI_STORE: return launch_gemm_t<T, EPI_STORE>(g, s);
+        case EPI_RESID: return launch_gemm_t<T, EPI_RESID>(g, s);
+        case EPI_PATCH: return launch_gemm_t<T, EPI_PATCH>(g, s);
+        default: return launch_gemm_t<T, EPI_F32>(g, s);
+    }
+}
+
+}  // namespace
+
+int ivr_launch_gemm(bool f32, int epi, const GemmArgs &g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return IVR_OK;
+    const int epr = f32 ? 32 : 64;
+    IVR_REQUIRE(g.K > 0 && g.K % epr == 0, "gemm: K=%d must be a multiple of %d", g.K, epr);
+    IVR_REQUIRE(g.N % 4 == 0, "gemm: N=%d must be a multiple of 4", g.N);
+    return f32 ? launch_gemm_e<float>(epi, g, s) : launch_gemm_e<unsigned short>(epi, g, s);
+}
+
+int ivr_launch_layernorm(bool out_f32, const float *x, int row_mul, const int *offs, const float *g, const float *b, float eps,
+                         void *out, int rows, int D, hipStream_t s) {
+    if (rows <= 0) return IVR_OK;
+    IVR_REQUIRE(D % 4 == 0 && D <= 2048, "layernorm: D=%d", D);
+    const unsigned grid = (unsigned)ivr_ceil_div(rows, 4);
+    if (out_f32)
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, x, row_mul, offs, g, b, eps, (float *)out, rows, D);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<unsigned short>, dim3(grid), dim3(256), 0, s, x, row_mul, offs, g, b, eps,
+                           (unsigned short *)out, rows, D);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int D, int heads, int causal, hipStream_t s) {
+    if (n <= 0) return IVR_OK;
+    const int threads = (int)ivr_round_up(T, 64);
+    IVR_REQUIRE(threads <= 512, "attention: T=%d too long for the short-sequence kernel", T);
+    const size_t lds = (size_t)2 * T * 64 * (f32 ? 4 : 2);
+    IVR_REQUIRE(lds <= 160 * 1024, "attention: T=%d needs %zu bytes of LDS", T, lds);
+    if (f32) {
+        IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        hipLaunchKernelGGL(attention_kernel<float>, dim3(heads, n), dim3(threads), lds, s, (const float *)qkv, (float *)att, T, D, causal);
+    } else {
+        IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<unsigned short>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(attention_kernel<unsigned short>, dim3(heads, n), dim3(threads), lds, s, (const unsigned short *)qkv,
+                           (unsigned short *)att, T, D, causal);
+    }
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+int ivr_launch_vision_cls(float *resid, const float *cls, const float *pos, int n, int T, int D, hipStream_t s) {
+    if (n <= 0) return IVR_OK;
+    hipLaunchKernelGGL(vision_cls_kernel, dim3(n), dim3(256), 0, s, resid, cls, pos, T, D);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+int ivr_launch_text_embed(float *resid, const int64_t *ids, const float *tok, const float *pos, int q, int T, int D, int vocab,
+                          int eos, int *eos_pos, hipStream_t s) {
+    if (q <= 0) return IVR_OK;
+    hipLaunchKernelGGL(text_embed_kernel, dim3(q * T), dim3(256), 0, s, resid, ids, tok, pos, T, D, vocab);
+    IVR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(eos_pos_kernel, dim3((unsigned)ivr_ceil_div(q, 256)), dim3(256), 0, s, ids, q, T, eos, eos_pos);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+int ivr_launch_f_normalize(const float *x, float *out, int n, int d, int normalize, hipStream_t s) {
+    if (n <= 0) return IVR_OK;
+    hipLaunchKernelGGL(f_normalize_kernel, dim3((unsigned)ivr_ceil_div(n, 4)), dim3(256), 0, s, x, out, n, d, normalize);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}

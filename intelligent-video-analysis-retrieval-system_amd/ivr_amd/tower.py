@@ -1,0 +1,113 @@
+"""Host wrapper of the HIP encoder towers (ivr_tower_*).
+
+Stands in for the HuggingFace modules the reference calls at `core.py:1619`
+(`CLIPModel.get_image_features`), `core.py:1541` (`get_text_features`) and
+`video_frame_filter.py:31` (`ViTModel`).  Weights are the float32 master dict of
+`ivr_amd.weights` (synthetic or converted from an HF state dict); GEMM operands are
+cast to bf16 at upload unless `compute="f32"` (verification mode).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .config import TowerConfig
+from .preprocess import preprocess_frames
+
+
+class Tower:
+    def __init__(self, cfg: TowerConfig, weights, max_batch=256, compute="bf16", device=None):
+        self._lib = _ffi.load()
+        self.cfg = cfg
+        self.compute = compute
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        self.max_batch = int(max_batch)
+        self.act_dtype = torch.bfloat16 if compute == "bf16" else torch.float32
+        d = _ffi.TowerDesc(kind=0 if cfg.kind == "vision" else 1, width=cfg.width, layers=cfg.layers, heads=cfg.heads,
+                           mlp=cfg.mlp, tokens=cfg.tokens, out_dim=cfg.out_dim, act=cfg.act, pool=cfg.pool,
+                           image=cfg.image, patch=cfg.patch, pre_ln=int(cfg.pre_ln), patch_bias=int(cfg.patch_bias),
+                           vocab=cfg.vocab, eos_id=cfg.eos_id, causal=int(cfg.causal),
+                           compute={"bf16": 0, "f32": 1}[compute], ln_eps=cfg.ln_eps)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _ffi.check(self._lib.ivr_tower_create(_ffi.context(self.device.index), C.byref(d), C.byref(h)),
+                       "ivr_tower_create")
+            self._h = h
+            for name, arr in weights.items():
+                a = np.ascontiguousarray(arr, dtype=np.float32)
+                _ffi.check(self._lib.ivr_tower_set_weight(h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size),
+                           f"ivr_tower_set_weight({name})")
+            _ffi.check(self._lib.ivr_tower_finalize(h, self.max_batch), "ivr_tower_finalize")
+
+    @property
+    def embed_dim(self):
+        return self.cfg.embed_dim
+
+    @property
+    def workspace_bytes(self):
+        return int(self._lib.ivr_tower_workspace_bytes(self._h))
+
+    # -- vision --------------------------------------------------------------------------------
+    def encode_patches(self, patches, n, normalize=True, out=None, capture_hidden=None):
+        """patches: CUDA patch-major pixels [n*g*g, Kpad] in the tower's activation dtype."""
+        if patches.dtype != self.act_dtype or not patches.is_cuda or not patches.is_contiguous():
+            raise ValueError(f"patches must be a contiguous CUDA {self.act_dtype} tensor")
+        if out is None:
+            out = torch.empty((n, self.embed_dim), dtype=torch.float32, device=self.device)
+        hidden = None
+        with torch.cuda.device(self.device):
+            if capture_hidden is not None:
+                hidden = torch.empty((n, self.cfg.tokens, self.cfg.width), dtype=torch.float32, device=self.device)
+                _ffi.check(self._lib.ivr_tower_debug_hidden(self._h, int(capture_hidden), n, C.c_void_p(hidden.data_ptr()),
+                                                            _ffi.stream_ptr()), "ivr_tower_debug_hidden")
+            _ffi.check(self._lib.ivr_tower_encode_image(self._h, C.c_void_p(patches.data_ptr()), int(n), int(bool(normalize)),
+                                                        C.c_void_p(out.data_ptr()), _ffi.stream_ptr()),
+                       "ivr_tower_encode_image")
+        return (out, hidden) if capture_hidden is not None else out
+
+    def encode_frames(self, frames, mode="identity", mean=None, std=None, bgr=False, normalize=True, out=None):
+        """uint8 [n,h,w,3] frames (numpy or CUDA) -> float32 CUDA [n, embed_dim]; batches of max_batch."""
+        from .config import CLIP_MEAN, CLIP_STD
+        mean = CLIP_MEAN if mean is None else mean
+        std = CLIP_STD if std is None else std
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(np.ascontiguousarray(frames))
+        n = frames.shape[0]
+        if out is None:
+            out = torch.empty((n, self.embed_dim), dtype=torch.float32, device=self.device)
+        for i in range(0, n, self.max_batch):
+            chunk = frames[i:i + self.max_batch]
+            if not chunk.is_cuda:
+                chunk = chunk.to(self.device)
+            px = preprocess_frames(chunk, mode, mean, std, bgr=bgr, size=self.cfg.image, patch=self.cfg.patch,
+                                   out_dtype=self.act_dtype)
+            self.encode_patches(px, chunk.shape[0], normalize, out=out[i:i + chunk.shape[0]])
+        return out
+
+    # -- text ----------------------------------------------------------------------------------
+    def encode_ids(self, ids, normalize=True):
+        """int64 token ids [q,T] (numpy or tensor) -> float32 CUDA [q, embed_dim]."""
+        if isinstance(ids, np.ndarray):
+            ids = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64))
+        ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
+        q, T = ids.shape
+        out = torch.empty((q, self.embed_dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            for i in range(0, q, self.max_batch):
+                sub = ids[i:i + self.max_batch].contiguous()
+                _ffi.check(self._lib.ivr_tower_encode_text(self._h, C.c_void_p(sub.data_ptr()), sub.shape[0], T,
+                                                           int(bool(normalize)), C.c_void_p(out[i:].data_ptr()),
+                                                           _ffi.stream_ptr()), "ivr_tower_encode_text")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ivr_tower_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
