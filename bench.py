@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py - the hot path of BASELINE.json on N GPUs of one node.
+
+Workload (config.workload): BASELINE.json configs[1] - ViT-B/32 bf16 random-init, ~100k synthetic 224x224 RGB
+frames embedded to 512-d, and a 1M-row x 512-d float32 index searched with 10 queries, top-10 - per GPU.
+A "step" is one pass of the whole path over one batch, inputs already resident in HBM:
+    uint8 NHWC frames --HIP preprocess--> bf16 patches --HIP ViT-B/32--> L2-normalised rows
+    --HIP append (ring overwrite)--> the 1M-row index --HIP cosine top-10--> (score, id) for 10 queries
+    [N > 1: one RCCL all-gather of the per-shard candidates + merge]
+value = frames embedded per second by the whole job (every frame also pays its share of the search);
+pairs_per_s = query x index-row cosines per second of the search part alone (HIP events), also reported.
+
+python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "intelligent-video-analysis-retrieval-system_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
+
+
+def cpu_baseline(cfg, weights, frames_u8, index_rows, queries, k, budget_s=20.0):
+    """The oracle (a port: the reference's own Python cannot travel) timed on this box's host
+    cores on a bounded sample of the same workload: fp32 ViT-B/32 in batches of 32 (core.py:1558) and the exact
+    inner-product top-k over a slice of the index."""
+    from oracle import preprocess_ref as P
+    from oracle import search_ref as S
+    from oracle import vit_ref as V
+    from ivr_amd import config as C
+    # threads actually used: this process's CPU share (the box has more logical cores than a 1-GPU job may use)
+    cores = min(len(os.sched_getaffinity(0)), 32)
+    torch.set_num_threads(cores)
+    px = P.preprocess(frames_u8[:32], "identity", C.CLIP_MEAN, C.CLIP_STD)
+    V.vision_forward(cfg, weights, px[:8])                       # warm-up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        emb = V.vision_forward(cfg, weights, px)
+        done += len(px)
+        if time.perf_counter() - t0 > budget_s * 0.75 or done >= 512:
+            break
+    t_embed = time.perf_counter() - t0
+    S.flat_ip_search(index_rows[:1000], queries, k)              # warm-up
+    t1 = time.perf_counter()
+    reps = 0
+    while True:
+        S.flat_ip_search(index_rows, queries, k)
+        reps += 1
+        if time.perf_counter() - t1 > budget_s * 0.25 or reps >= 20:
+            break
+    t_search = (time.perf_counter() - t1) / reps
+    return {"value": done / t_embed, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{done} frames of 224x224 through the fp32 oracle ViT-B/32 in batches of 32 "
+                      f"({t_embed:.1f} s); exact IP top-{k} of {len(queries)} queries over {len(index_rows)} x "
+                      f"{index_rows.shape[1]} rows, {reps} repeats",
+            "pairs_per_s": len(index_rows) * len(queries) / t_search, "threads": torch.get_num_threads(), "emb_dim": int(emb.shape[1])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=49)           # 49 x 2048 = 100,352 frames (configs[1]: 100k)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-step", type=int, default=2048)
+    ap.add_argument("--index-rows", type=int, default=1_000_000)
+    ap.add_argument("--queries", type=int, default=10)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ivr_amd import _ffi
+    from ivr_amd import config as C
+    from ivr_amd.index import FlatIPIndex
+    from ivr_amd.preprocess import preprocess_frames
+    from ivr_amd.sharded import ShardedIndex
+    from ivr_amd.tower import Tower
+    from ivr_amd.weights import make_weights
+
+    cfg = C.CLIP_VIT_B32
+    B, N, Q, k = args.frames_per_step, args.index_rows, args.queries, args.k
+    weights = make_weights(cfg, 12)
+    tower = Tower(cfg, weights, max_batch=B, compute="bf16", device=local_rank)
+
+    # synthetic inputs, generated on the device (a 100k-frame host array would be 15 GB)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    frame_tiles = [torch.randint(0, 256, (B, 224, 224, 3), generator=g, device=dev, dtype=torch.uint8) for _ in range(2)]
+    index = FlatIPIndex(512, capacity=N, device=local_rank)
+    gi = torch.Generator(device=dev).manual_seed(5678 + rank)
+    for i in range(0, N, 250_000):
+        rows = torch.randn((min(250_000, N - i), 512), generator=gi, device=dev, dtype=torch.float32)
+        index.add(rows, normalize=True)
+        del rows
+    queries = torch.from_numpy(np.random.default_rng(91011).standard_normal((Q, 512), dtype=np.float32)).to(dev)
+    index.reserve_search(Q, k)
+    sharded = ShardedIndex(index, 512, merge="device")
+    sharded.sync_counts()
+
+    patches = torch.empty((B * 49, 3072), dtype=torch.bfloat16, device=dev)
+    emb = torch.empty((B, 512), dtype=torch.float32, device=dev)
+    ring = {"pos": 0}
+    ev_s0, ev_s1 = [], []
+
+    def step(i, timed):
+        preprocess_frames(frame_tiles[i & 1], "identity", C.CLIP_MEAN, C.CLIP_STD, size=224, patch=32, out=patches)
+        tower.encode_patches(patches, B, normalize=True, out=emb)
+        pos = ring["pos"]
+        index.write_device(pos, emb)          # rows are already L2-normalised by the tower epilogue
+        ring["pos"] = (pos + B) % (N - B + 1) if N > B else 0
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        D, I = sharded.search(queries, k, normalize=True)
+        if timed:
+            e1.record()
+            ev_s0.append(e0)
+            ev_s1.append(e1)
+        return D, I
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    barrier()
+    _ffi.profile_reset(local_rank)
+    _ffi.profile_enable(True, local_rank)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        D, I = step(i, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _ffi.profile_enable(False, local_rank)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = _ffi.profile_read(local_rank)
+    search_ms = sum(a.elapsed_time(b) for a, b in zip(ev_s0, ev_s1)) / max(1, len(ev_s0))
+
+    if rank == 0:
+        frames_total = B * args.steps * world
+        gemm = {n: v for n, v in prof.items() if n.startswith("gemm_")}
+        gemm_flop = sum(v["work"] for v in gemm.values())
+        gemm_ms = sum(v["ms"] for v in gemm.values())
+        gemm_launches = sum(v["launches"] for v in gemm.values())
+        gemm_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms else 0.0
+
+        def hbm(name):
+            v = prof.get(name)
+            if not v or not v["ms"]:
+                return None
+            a = v["work"] / (v["ms"] * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": name, "avg_launch_ms": v["ms"] / v["launches"], "launches": int(v["launches"]),
+                    "bytes_per_launch": v["work"] / v["launches"]}
+
+        out = {
+            "metric": "frames/s embedded (+ query-vs-index cosine pairs/s; top-10 recall vs CPU ref)",
+            "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: ViT-B/32 bf16 random-init embed of 224x224 RGB frames + 1M-row x 512-d "
+                                   "fp32 index cosine top-10 (per GPU)",
+                       "frames_per_step_per_gpu": B, "frames_total": frames_total, "index_rows_per_gpu": N, "queries": Q, "k": k,
+                       "parallelism": f"{world} x (frames + index rows sharded per GPU); one all-gather of (score,id) + merge"},
+            "pairs_per_s": N * world * Q / (search_ms * 1e-3), "search_ms_per_step": search_ms,
+            "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TF,
+                         "traffic": None, "kernel": "gemm_kernel<bf16> (all tower GEMM launches of the timed region)",
+                         "avg_launch_ms": gemm_ms / max(1, gemm_launches), "launches": int(gemm_launches),
+                         "flop_per_launch": gemm_flop / max(1, gemm_launches),
+                         "by_call_site": {n: {"TFLOP/s": v["work"] / (v["ms"] * 1e-3) / 1e12, "ms": v["ms"] / v["launches"]}
+                                          for n, v in sorted(gemm.items())}},
+            "roofline_search": hbm("scan_groupmax"),
+            "roofline_preprocess": hbm("preprocess_emit"),
+            "kernel_ms_per_step": {n: v["ms"] / args.steps for n, v in sorted(prof.items())},
+        }
+        # recall / id check of the last search against the oracle (rank 0's shard; N == 1: the whole index)
+        from oracle import search_ref as S
+        Xh = index.reconstruct_n(0, N)
+        qn = S.normalize_rows_core(queries.cpu().numpy()).astype(np.float32)
+        Dl, Il = index.search_device(queries, k, normalize=True)
+        Dr, Ir = S.flat_ip_search(Xh, qn, k, dtype=np.float64)
+        Il, Dl = Il.cpu().numpy(), Dl.cpu().numpy()
+        out["recall_at_10"] = float(np.mean([len(set(Il[q]) & set(Ir[q])) / k for q in range(Q)]))
+        out["ids_exact"] = bool(np.array_equal(Il, Ir))
+        out["max_abs_score_err"] = float(np.abs(Dl - Dr).max())
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, frame_tiles[0][:32].cpu().numpy(), Xh[:100_000], qn, k)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

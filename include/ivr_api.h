@@ -55,6 +55,15 @@ int ivr_destroy(ivr_ctx *ctx);
 const char *ivr_last_error(ivr_ctx *ctx);       /* ctx may be NULL */
 int ivr_device_info(ivr_ctx *ctx, int *cu_count, int64_t *hbm_bytes, char *arch, int arch_len);
 
+/* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the launch stream ---------------
+ * No counterpart in the reference (its only profiler is the wall-clock PerformanceMonitor.timer,
+ * utils.py:2481).  When enabled every kernel launch is bracketed by two events; ivr_profile_json
+ * synchronises on them and writes {"kernel": {"launches", "ms", "work"}} where work is the launch's
+ * algorithmic bytes (HBM-bound kernels) or FLOP (MFMA-bound kernels). */
+int ivr_profile_enable(ivr_ctx *ctx, int on);
+int ivr_profile_reset(ivr_ctx *ctx);
+int ivr_profile_json(ivr_ctx *ctx, char *buf /*HOST*/, int len);
+
 /* ---- P1 / P2: frame preprocessing -------------------------------------------------------------
  * Replaces HFCLIPProcessor(images=...) at core.py:1613 and
  * cv2.cvtColor + Image.resize + processor(...) at video_frame_filter.py:58-59,29.
@@ -115,6 +124,15 @@ int ivr_tower_encode_text(ivr_tower *t, const int64_t *ids /*DEV*/, int q, int T
  * `layer` blocks (0 = embeddings) into out as f32 [n,T,width]. */
 int ivr_tower_debug_hidden(ivr_tower *t, int layer, int n, float *out /*DEV*/, ivr_stream stream);
 int64_t ivr_tower_workspace_bytes(ivr_tower *t);
+
+/* Building block of the towers, exposed for parity tests and kernel benchmarks: y = x W^T (+ bias), i.e. the
+ * nn.Linear calls inside the HF modules (modeling_clip.py:259-277, 338-350).  x: DEV [M,K], w: DEV [N,K], both
+ * bf16 (f32_mode = 0) or float32 (f32_mode = 1); bias: DEV float32 [N] or NULL.  K must be a multiple of 64 (32 in f32 mode),
+ * N of 4.  epilogue 0: out = act(y) in the operand dtype (act = -1 none, else IVR_ACT_*); 1: resid (DEV float32 [M,N]) += y;
+ * 3: out = y as float32. */
+int ivr_linear(ivr_ctx *ctx, int f32_mode, int epilogue, const void *x /*DEV*/, const void *w /*DEV*/,
+               const float *bias /*DEV*/, int M, int N, int K, int act, void *out /*DEV*/, float *resid /*DEV*/,
+               ivr_stream stream);
 
 /* ---- N2 / N3: row L2 normalisation -------------------------------------------------------------
  * Replaces FAISSRetriever._normalize_and_validate_features (core.py:1176-1196) and

@@ -43,6 +43,22 @@ int ivr_fail(int code, const char *fmt, ...);
 
 int ivr_ctx_scratch(ivr_ctx *ctx, size_t bytes, void **out);
 
+// Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline figures).
+// `work` is the launch's algorithmic work: bytes for HBM-bound kernels, FLOP for MFMA-bound ones.
+bool ivr_prof_on();
+void ivr_prof_begin(const char *name, hipStream_t s, double work);
+void ivr_prof_end(hipStream_t s);
+struct IvrProf {
+    hipStream_t s;
+    bool on;
+    IvrProf(const char *name, hipStream_t st, double work) : s(st), on(ivr_prof_on()) {
+        if (on) ivr_prof_begin(name, s, work);
+    }
+    ~IvrProf() {
+        if (on) ivr_prof_end(s);
+    }
+};
+
 static inline int64_t ivr_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t ivr_round_up(int64_t a, int64_t b) { return ivr_ceil_div(a, b) * b; }
 

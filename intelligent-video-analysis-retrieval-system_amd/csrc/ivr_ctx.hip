@@ -1,7 +1,10 @@
 // Context, error slot and scratch management for libivr_hip.so.
 #include "ivr_common.h"
 
+#include <array>
+#include <atomic>
 #include <cstring>
+#include <vector>
 
 std::string &ivr_err_slot() {
     static thread_local std::string s;
@@ -32,7 +35,96 @@ int ivr_ctx_scratch(ivr_ctx *ctx, size_t bytes, void **out) {
     return IVR_OK;
 }
 
+namespace {
+struct ProfEntry {
+    std::string name;
+    double work;
+    hipEvent_t a, b;
+};
+struct Prof {
+    std::mutex mu;
+    std::atomic<bool> on{false};
+    std::vector<ProfEntry> entries;
+    std::vector<hipEvent_t> pool;
+};
+Prof &prof() {
+    static Prof p;
+    return p;
+}
+hipEvent_t prof_event(Prof &p) {
+    if (!p.pool.empty()) {
+        hipEvent_t e = p.pool.back();
+        p.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+bool ivr_prof_on() { return prof().on.load(std::memory_order_relaxed); }
+
+void ivr_prof_begin(const char *name, hipStream_t s, double work) {
+    Prof &p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    ProfEntry e{name, work, prof_event(p), prof_event(p)};
+    (void)hipEventRecord(e.a, s);
+    p.entries.push_back(e);
+}
+
+void ivr_prof_end(hipStream_t s) {
+    Prof &p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (!p.entries.empty()) (void)hipEventRecord(p.entries.back().b, s);
+}
+
 extern "C" {
+
+int ivr_profile_enable(ivr_ctx *, int on) {
+    prof().on.store(on != 0);
+    return IVR_OK;
+}
+
+int ivr_profile_reset(ivr_ctx *) {
+    Prof &p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    for (auto &e : p.entries) {
+        p.pool.push_back(e.a);
+        p.pool.push_back(e.b);
+    }
+    p.entries.clear();
+    return IVR_OK;
+}
+
+// JSON: {"name": {"launches": n, "ms": total, "work": total}, ...}; synchronises on the recorded events
+int ivr_profile_json(ivr_ctx *, char *buf, int len) {
+    IVR_REQUIRE(buf && len > 2, "ivr_profile_json: bad buffer");
+    Prof &p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    std::map<std::string, std::array<double, 3>> agg;
+    for (auto &e : p.entries) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.b) != hipSuccess || hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) continue;
+        auto &a = agg[e.name];
+        a[0] += 1;
+        a[1] += ms;
+        a[2] += e.work;
+    }
+    std::string out = "{";
+    bool first = true;
+    for (auto &kv : agg) {
+        char tmp[256];
+        snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"launches\": %.0f, \"ms\": %.6f, \"work\": %.6e}", first ? "" : ", ",
+                 kv.first.c_str(), kv.second[0], kv.second[1], kv.second[2]);
+        out += tmp;
+        first = false;
+    }
+    out += "}";
+    IVR_REQUIRE((int)out.size() + 1 <= len, "ivr_profile_json: buffer of %d bytes too small for %zu", len, out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return IVR_OK;
+}
 
 int ivr_api_version(void) { return IVR_API_VERSION; }
 

@@ -359,9 +359,9 @@ int64_t ivr_preprocess_scratch_bytes(int n, int h, int w, int flags, int out_siz
 
 int ivr_preprocess(ivr_ctx *ctx, const uint8_t *src, int n, int h, int w, int flags, const float mean[3], const float std[3],
                    int out_size, int patch, void *dst, ivr_stream stream) {
-    IVR_REQUIRE(ctx && src && dst && mean && std, "ivr_preprocess: NULL argument");
+    IVR_REQUIRE(ctx && mean && std, "ivr_preprocess: NULL argument");
     IVR_REQUIRE(n >= 0 && h >= 1 && w >= 1, "ivr_preprocess: n=%d h=%d w=%d", n, h, w);
-    if (n == 0) return IVR_OK;
+    IVR_REQUIRE(n == 0 || (src && dst), "ivr_preprocess: NULL frame buffer");
     const int S = out_size;
     const int mode = flags & IVR_PP_MODE_MASK;
     const bool patch_major = flags & IVR_PP_OUT_PATCH_MAJOR;
@@ -372,6 +372,7 @@ int ivr_preprocess(ivr_ctx *ctx, const uint8_t *src, int n, int h, int w, int fl
     IVR_REQUIRE(mode != IVR_PP_MODE_IDENTITY || (h == S && w == S), "ivr_preprocess: identity mode needs %dx%d frames, got %dx%d",
                 S, S, h, w);
     for (int c = 0; c < 3; ++c) IVR_REQUIRE(std[c] != 0.f, "ivr_preprocess: std[%d] is zero", c);
+    if (n == 0) return IVR_OK;
     IVR_HIP(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
 
@@ -462,6 +463,8 @@ int ivr_preprocess(ivr_ctx *ctx, const uint8_t *src, int n, int h, int w, int fl
         }
         d_lut = it->second;
     }
+    // algorithmic bytes: uint8 canvas in, normalised elements out
+    IvrProf prof("preprocess_emit", s, (double)n * S * S * 3 * (1 + (f32_out ? 4 : 2)));
     if (P % 8 == 0) {
         ep.R = P <= 32 ? P : 8;
         IVR_REQUIRE(S % ep.R == 0, "ivr_preprocess: out_size %d not divisible by row block %d", S, ep.R);

@@ -456,6 +456,7 @@ int launch_tile_rows(ivr_index *x, float *dst, const float *src, int64_t start, 
     if (n <= 0) return IVR_OK;
     const int64_t ntiles = ((start + n + 15) >> 4) - (start >> 4);
     const unsigned grid = (unsigned)ivr_ceil_div(ntiles, 4);
+    IvrProf prof("tile_rows", s, (double)n * (x->d + x->dp) * 4);
     hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, src, dst, start, n, x->d, x->dp4, normalize, nonfinite);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
@@ -509,6 +510,8 @@ void launch_scan(ivr_index *x, const float *qt, int64_t ngroups, int64_t mstride
     grid = std::max<int64_t>(grid, 1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scan_groupmax_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
+    // algorithmic bytes: every stored row once + the query tile + one maximum per (group, query)
+    IvrProf prof("scan_groupmax", s, (double)x->ntotal * x->dp * 4 + (double)QT * 16 * x->dp * 4 + (double)ngroups * QT * 16 * 4);
     hipLaunchKernelGGL(scan_groupmax_kernel<QT>, dim3((unsigned)grid), dim3(threads), lds, s, x->data, qt, x->dp4, ngroups,
                        x->ntotal, x->gmax, mstride);
 }
@@ -647,15 +650,22 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
             IVR_LAUNCH_CHECK();
         }
         SrcGroupMax sg{x->gmax, mstride, ngroups};
+        {
+        IvrProf prof("select_groups", s, (double)nqc * ngroups * 4);
         hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(kSelThreads), 0, s, sg, 0, ksel,
                            (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr);
+        }
         IVR_LAUNCH_CHECK();
         const int64_t waves = (int64_t)nqc * ksel;
         // rescore reads query tile (q >> 4) relative to the chunk's first tile
+        {
+        IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4);
         hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)ivr_ceil_div(waves, 4)), dim3(256), 0, s, x->data, qtile,
                            x->dp4, x->ntotal, x->sel, ksel, nqc, x->cand);
+        }
         IVR_LAUNCH_CHECK();
         SrcKeys sk{x->cand, (int64_t)ksel * kGroupRows};
+        IvrProf prof("select_final", s, (double)waves * kGroupRows * 8);
         hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(kSelThreads), 0, s, sk, 0, k, id_base,
                            (uint32_t *)nullptr, D + (int64_t)q0 * k, I + (int64_t)q0 * k, (const int64_t *)nullptr);
         IVR_LAUNCH_CHECK();

@@ -159,6 +159,7 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.bias = wptr<float>(t, p + "qkv_b");
         g.out = t->qkv;
         g.ldo = 3 * D;
+        g.tag = "gemm_qkv";
         rc = ivr_launch_gemm(f32, EPI_STORE, g, s);
         if (rc) return rc;
         rc = ivr_launch_attention(f32, t->qkv, t->att, n, T, D, d.heads, d.causal, s);
@@ -174,6 +175,7 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.bias = wptr<float>(t, p + "o_b");
         g.resid = t->resid;
         g.ldr = D;
+        g.tag = "gemm_attn_out";
         rc = ivr_launch_gemm(f32, EPI_RESID, g, s);
         if (rc) return rc;
         rc = ivr_launch_layernorm(f32, t->resid, 1, nullptr, wptr<float>(t, p + "ln2_g"), wptr<float>(t, p + "ln2_b"), d.ln_eps,
@@ -191,6 +193,7 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.out = t->hid;
         g.ldo = d.mlp;
         g.act = d.act;
+        g.tag = "gemm_fc1";
         rc = ivr_launch_gemm(f32, EPI_STORE, g, s);
         if (rc) return rc;
         g = GemmArgs();
@@ -204,6 +207,7 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.bias = wptr<float>(t, p + "fc2_b");
         g.resid = t->resid;
         g.ldr = D;
+        g.tag = "gemm_fc2";
         rc = ivr_launch_gemm(f32, EPI_RESID, g, s);
         if (rc) return rc;
     }
@@ -238,6 +242,7 @@ int run_pool(ivr_tower *t, int n, int T, const int *offs, int normalize, float *
     g.K = D;
     g.out = t->pooled_f32;
     g.ldo = d.out_dim;
+    g.tag = "gemm_proj";
     rc = ivr_launch_gemm(f32, EPI_F32, g, s);
     if (rc) return rc;
     return ivr_launch_f_normalize(t->pooled_f32, out, n, d.out_dim, normalize, s);
@@ -373,6 +378,7 @@ int ivr_tower_encode_image(ivr_tower *t, const void *patches, int n, int normali
     g.pos = wptr<float>(t, "pos");
     g.T = T;
     g.G2 = G2;
+    g.tag = "gemm_patch";
     rc = ivr_launch_gemm(f32, EPI_PATCH, g, s);
     if (rc) return rc;
     if (d.pre_ln) {
@@ -403,6 +409,31 @@ int ivr_tower_encode_text(ivr_tower *t, const int64_t *ids, int q, int T, int no
     rc = run_layers(t, q, T, s);
     if (rc) return rc;
     return run_pool(t, q, T, t->eos_pos, normalize, out, s);
+}
+
+int ivr_linear(ivr_ctx *ctx, int f32_mode, int epilogue, const void *x, const void *w, const float *bias, int M, int N, int K, int act,
+               void *out, float *resid, ivr_stream stream) {
+    IVR_REQUIRE(ctx && x && w, "ivr_linear: NULL argument");
+    IVR_REQUIRE(epilogue == EPI_STORE || epilogue == EPI_RESID || epilogue == EPI_F32, "ivr_linear: epilogue=%d", epilogue);
+    IVR_REQUIRE(M >= 0 && N >= 4 && K >= 1, "ivr_linear: M=%d N=%d K=%d", M, N, K);
+    IVR_REQUIRE(epilogue == EPI_RESID ? resid != nullptr : out != nullptr, "ivr_linear: NULL output");
+    IVR_HIP(hipSetDevice(ctx->device));
+    GemmArgs g;
+    g.A = x;
+    g.lda = K;
+    g.W = w;
+    g.ldw = K;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.bias = bias;
+    g.out = out;
+    g.ldo = N;
+    g.resid = resid;
+    g.ldr = N;
+    g.act = act;
+    g.tag = "linear";
+    return ivr_launch_gemm(f32_mode != 0, epilogue, g, (hipStream_t)stream);
 }
 
 int ivr_tower_debug_hidden(ivr_tower *t, int layer, int n, float *out, ivr_stream) {

@@ -18,6 +18,7 @@ struct GemmArgs {
     const float *pos = nullptr;    // EPI_PATCH: position embedding [T,N]
     int T = 0, G2 = 0;             // tokens per image, patches per image
     int act = -1;                  // EPI_STORE: -1 none, else IVR_ACT_*
+    const char *tag = nullptr;     // profiler name of this call site
 };
 
 int ivr_launch_gemm(bool f32, int epi, const GemmArgs &g, hipStream_t s);

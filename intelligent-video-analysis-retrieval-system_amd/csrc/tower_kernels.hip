@@ -237,14 +237,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     for (int kt = 0; kt < KT; ++kt) {
         unsigned char *cur = smem + (kt & 1) * 2 * TILE_BYTES;
         unsigned char *nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-        const bool more = kt + 1 < KT;
-        if (more) {
-            const int64_t adv = (int64_t)(kt + 1) * ROWB;
+        // unconditional prefetch (the last trip re-loads the last tile into the idle buffer): keeping the staging
+        // registers out of any branch lets them stay in VGPRs and the loads stay in flight under the MFMAs
+        const int64_t adv = (int64_t)min(kt + 1, KT - 1) * ROWB;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                rx[j] = *reinterpret_cast<const uint4 *>(srcX[j] + adv);
-                rw[j] = *reinterpret_cast<const uint4 *>(srcW[j] + adv);
-            }
+        for (int j = 0; j < 4; ++j) {
+            rx[j] = *reinterpret_cast<const uint4 *>(srcX[j] + adv);
+            rw[j] = *reinterpret_cast<const uint4 *>(srcW[j] + adv);
         }
         const unsigned char *xs = cur + (wm * 64) * ROWB, *ws = cur + TILE_BYTES + (wn * 64) * ROWB;
 #pragma unroll
@@ -260,12 +259,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(wf[nt], xf[mt], acc[nt][mt]);
         }
-        if (more) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<uint4 *>(nxt + dst[j]) = rx[j];
-                *reinterpret_cast<uint4 *>(nxt + TILE_BYTES + dst[j]) = rw[j];
-            }
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<uint4 *>(nxt + dst[j]) = rx[j];
+            *reinterpret_cast<uint4 *>(nxt + TILE_BYTES + dst[j]) = rw[j];
         }
         __syncthreads();
     }
@@ -419,6 +416,7 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
                                     GEMM_LDS));
         attr_done = true;
     }
+    IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
     hipLaunchKernelGGL((gemm_kernel<T, EPI>), dim3(MT * NT), dim3(256), GEMM_LDS, s, g);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
@@ -449,6 +447,7 @@ int ivr_launch_layernorm(bool out_f32, const float *x, int row_mul, const int *o
     if (rows <= 0) return IVR_OK;
     IVR_REQUIRE(D % 4 == 0 && D <= 2048, "layernorm: D=%d", D);
     const unsigned grid = (unsigned)ivr_ceil_div(rows, 4);
+    IvrProf prof("layernorm", s, (double)rows * D * (4 + (out_f32 ? 4 : 2)));
     if (out_f32)
         hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, x, row_mul, offs, g, b, eps, (float *)out, rows, D);
     else
@@ -464,6 +463,8 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
     IVR_REQUIRE(threads <= 512, "attention: T=%d too long for the short-sequence kernel", T);
     const size_t lds = (size_t)2 * T * 64 * (f32 ? 4 : 2);
     IVR_REQUIRE(lds <= 160 * 1024, "attention: T=%d needs %zu bytes of LDS", T, lds);
+    // FLOP: QK^T and PV, 2*T*T*64 each per (image, head)
+    IvrProf prof("attention", s, 4.0 * n * heads * (double)T * T * 64);
     if (f32) {
         IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));

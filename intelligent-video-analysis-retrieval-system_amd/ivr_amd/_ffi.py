@@ -32,6 +32,9 @@ _SIGS = {
     "ivr_destroy": (_i, [_p]),
     "ivr_last_error": (C.c_char_p, [_p]),
     "ivr_device_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i64), C.c_char_p, _i]),
+    "ivr_profile_enable": (_i, [_p, _i]),
+    "ivr_profile_reset": (_i, [_p]),
+    "ivr_profile_json": (_i, [_p, C.c_char_p, _i]),
     "ivr_preprocess": (_i, [_p, _p, _i, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _i, _i, _p, _p]),
     "ivr_preprocess_scratch_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "ivr_tower_create": (_i, [_p, C.POINTER(TowerDesc), C.POINTER(_p)]),
@@ -42,6 +45,7 @@ _SIGS = {
     "ivr_tower_encode_text": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "ivr_tower_debug_hidden": (_i, [_p, _i, _i, _p, _p]),
     "ivr_tower_workspace_bytes": (_i64, [_p]),
+    "ivr_linear": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "ivr_l2_normalize": (_i, [_p, _p, _i64, _i, _p, _p]),
     "ivr_index_create": (_i, [_p, _i, _i64, C.POINTER(_p)]),
     "ivr_index_destroy": (_i, [_p]),
@@ -75,6 +79,9 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                   "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+            # torch must load its HIP runtime first: the process has to end up with ONE libamdhip64, the one
+            # torch's allocator and streams live in (loading ours first leaves two runtimes and no visible device)
+            import torch  # noqa: F401
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in _SIGS.items():
                 fn = getattr(lib, name)
@@ -129,3 +136,19 @@ def stream_ptr(stream=None):
 
 def f3(v):
     return (_f * 3)(*[float(x) for x in v])
+
+
+def profile_enable(on=True, device=0):
+    check(load().ivr_profile_enable(context(device), int(bool(on))))
+
+
+def profile_reset(device=0):
+    check(load().ivr_profile_reset(context(device)))
+
+
+def profile_read(device=0):
+    """{"kernel": {"launches", "ms", "work"}} measured with HIP events on the launch stream."""
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    check(load().ivr_profile_json(context(device), buf, len(buf)))
+    return json.loads(buf.value.decode())

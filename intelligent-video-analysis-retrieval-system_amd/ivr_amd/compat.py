@@ -1,0 +1,693 @@
+"""Host-side mirror of the reference's hot-path interface.
+
+The reference has no plugin API: `core.py`, `system.py` and `unified_builder.py` hold duck-typed
+objects and call a handful of methods on them.  The classes below keep those names, argument
+meanings, return shapes and error behaviour, and route the arithmetic to libivr_hip.so:
+
+  reference object / function                              here
+  ------------------------------------------------------  ---------------------------------------------
+  core.CLIPFeatureExtractor            (core.py:1384)      CLIPFeatureExtractor
+  core.FAISSRetriever                  (core.py:687)       FAISSRetriever
+  core.KeyframeMetadata / SearchResult (core.py:84,161)    KeyframeMetadata / SearchResult
+  unified_index.UnifiedIndex           (unified_index.py:63)   UnifiedIndex (+ README aliases build_index /
+                                                               augmented_search, README.md:124-136)
+  unified_builder.UnifiedBuilderIntegration (unified_builder.py:26)  UnifiedBuilderIntegration
+  video_frame_filter.extract_embedding / extract_unique_frames (:28,:35)  same names, + FrameFilter alias
+  faiss.IndexFlatIP / faiss.normalize_L2                   ivr_amd.index.IndexFlatIP / normalize_L2
+
+Out of scope here, as in SURVEY.md section 8: HDF5/LZ4 container, thumbnails, resume, LLM, GUI, network.
+The index container written by `create_unified_index` is a plain .npz (vectors + JSON metadata).
+"""
+import csv
+import json
+import os
+import threading
+import time
+from dataclasses import asdict, dataclass
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import config as C
+from .dedup import DedupState
+from .index import FlatIPIndex, count_nonfinite_and_normalize
+from .tower import Tower
+from .weights import from_hf_state_dict, make_weights
+
+
+# ----------------------------------------------------------------------------------------------
+# data models (field layout of core.py:84-172; part of the boundary because callers read them)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class KeyframeMetadata:
+    folder_name: str
+    image_name: str
+    frame_id: int
+    file_path: str
+    sequence_position: int = 0
+    total_frames: int = 0
+    neighboring_frames: List[int] = None
+    scene_boundaries: List[Tuple[int, int]] = None
+    clip_features: Optional[np.ndarray] = None
+    llm_description: Optional[str] = None
+    detected_objects: List[str] = None
+    scene_tags: List[str] = None
+    confidence_score: float = 0.0
+    similar_frames: List[str] = None
+    transition_frames: List[str] = None
+
+    def __post_init__(self):
+        for f in ("neighboring_frames", "scene_boundaries", "detected_objects", "scene_tags", "similar_frames",
+                  "transition_frames"):
+            if getattr(self, f) is None:
+                setattr(self, f, [])
+        self._validate()
+
+    def _validate(self):
+        if not self.folder_name or not isinstance(self.folder_name, str):
+            raise ValueError("folder_name must be a non-empty string")
+        if not self.image_name or not isinstance(self.image_name, str):
+            raise ValueError("image_name must be a non-empty string")
+        if not isinstance(self.frame_id, int):
+            raise ValueError("frame_id must be an integer")
+        if not self.file_path or not isinstance(self.file_path, str):
+            raise ValueError("file_path must be a non-empty string")
+
+    def to_dict(self):
+        data = asdict(self)
+        if self.clip_features is not None:
+            data["clip_features"] = np.asarray(self.clip_features).tolist()
+        return data
+
+    @classmethod
+    def from_dict(cls, data):
+        data = dict(data)
+        if data.get("clip_features") is not None:
+            data["clip_features"] = np.array(data["clip_features"])
+        return cls(**data)
+
+    def get_unique_key(self):
+        return f"{self.folder_name}_{self.image_name}"
+
+
+@dataclass
+class SearchResult:
+    metadata: KeyframeMetadata
+    similarity_score: float
+    rank: int
+    query_relevance: float = 0.0
+    temporal_context: List["SearchResult"] = None
+    explanation: Optional[str] = None
+
+    def __post_init__(self):
+        if self.temporal_context is None:
+            self.temporal_context = []
+
+
+class _NullLogger:
+    def __getattr__(self, _):
+        return lambda *a, **k: None
+
+
+def _frame_id_of(name):
+    digits = "".join(ch for ch in os.path.splitext(name)[0] if ch.isdigit())
+    return int(digits) if digits else 0
+
+
+# ----------------------------------------------------------------------------------------------
+# CLIPFeatureExtractor
+# ----------------------------------------------------------------------------------------------
+class ByteTokenizer:
+    """Stand-in used only when no CLIP BPE vocabulary is available offline: [BOS, utf-8 bytes + 1 ..., EOS, EOS pad].
+    Row format matches what the CLIP tokenizer emits (core.py:1532-1538: pad, truncate to 77, EOS-padded)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def __call__(self, texts, max_length=77):
+        T = min(max_length, self.cfg.tokens)
+        ids = np.full((len(texts), T), self.cfg.eos_id, dtype=np.int64)
+        for r, t in enumerate(texts):
+            b = [1 + x for x in t.encode("utf-8")][:T - 2]
+            ids[r, 0] = self.cfg.eos_id - 1
+            ids[r, 1:1 + len(b)] = b
+        return ids
+
+
+class CLIPFeatureExtractor:
+    """core.py:1384.  `weights`/`text_weights`: canonical float32 dicts (ivr_amd.weights), a HF state dict, or None
+    for seeded random-init weights of the named architecture (no network for checkpoints)."""
+
+    ARCH = {"openai/clip-vit-base-patch32": (C.CLIP_VIT_B32, C.CLIP_TEXT_B32),
+            "openai/clip-vit-large-patch14": (C.CLIP_VIT_L14, C.CLIP_TEXT_L14)}
+
+    def __init__(self, model_path="openai/clip-vit-large-patch14", config=None, logger=None, weights=None,
+                 text_weights=None, tokenizer=None, max_batch=256, compute="bf16", seed=0, with_text=True):
+        self.config = config
+        self.logger = logger or _NullLogger()
+        self.model_path = model_path
+        if not torch.cuda.is_available():
+            raise RuntimeError("CLIPFeatureExtractor: no MI355X visible and there is no CPU fallback")
+        self.device = "cuda"
+        self.max_batch_size = 32          # core.py:1420 (the reference's processing granularity)
+        self.max_text_length = 77
+        vis_cfg, txt_cfg = self.ARCH.get(model_path, self.ARCH["openai/clip-vit-large-patch14"])
+        self.vision_config, self.text_config = vis_cfg, txt_cfg
+        self._lock = threading.RLock()    # encode_images is called from 4 worker threads (unified_index.py:773)
+        w = self._resolve(vis_cfg, weights, seed)
+        self.vision_model = Tower(vis_cfg, w, max_batch=max_batch, compute=compute)
+        self.text_model = None
+        if with_text:
+            tw = self._resolve(txt_cfg, text_weights, seed + 1)
+            self.text_model = Tower(txt_cfg, tw, max_batch=64, compute=compute)
+        self.model = self.vision_model    # truthy: health check at system.py:263
+        self.processor = tokenizer or ByteTokenizer(txt_cfg)
+        self.nlp = None
+
+    @staticmethod
+    def _resolve(cfg, weights, seed):
+        if weights is None:
+            return make_weights(cfg, seed)
+        if any(k.startswith(("vision_model.", "text_model.", "embeddings.")) for k in weights):
+            return from_hf_state_dict(cfg, weights)
+        return weights
+
+    # -- text (core.py:1504-1554) --------------------------------------------------------------
+    def _validate_and_clean_text(self, text):
+        out = []
+        for t in text:
+            if isinstance(t, str) and t.strip():
+                out.append(" ".join(t.split()))
+        return out
+
+    def encode_text(self, text: Union[str, List[str]], validate_input: bool = True) -> np.ndarray:
+        if isinstance(text, str):
+            text = [text]
+        if validate_input:
+            text = self._validate_and_clean_text(text)
+        if len(text) == 0:
+            raise ValueError("No valid text provided for encoding")
+        if self.text_model is None:
+            raise RuntimeError("Text encoding failed: extractor was built with with_text=False")
+        try:
+            with self._lock:
+                ids = np.asarray(self.processor(list(text), max_length=self.max_text_length), dtype=np.int64)
+                return self.text_model.encode_ids(ids, normalize=True).cpu().numpy()
+        except Exception as e:
+            raise RuntimeError(f"Text encoding failed: {e}")
+
+    # -- images (core.py:1556-1641) ------------------------------------------------------------
+    def _validate_image_paths(self, image_paths):
+        return [p for p in image_paths if isinstance(p, str) and os.path.isfile(p)]
+
+    def _load_and_validate_image(self, path):
+        from PIL import Image
+        img = Image.open(path).convert("RGB")             # core.py:1852
+        if img.size[0] < 32 or img.size[1] < 32:           # core.py:1855
+            return None
+        return img
+
+    def encode_images(self, image_paths: List[str], batch_size: int = 32, validate_files: bool = True,
+                      show_progress: bool = True) -> np.ndarray:
+        if len(image_paths) == 0:
+            raise ValueError("No image paths provided")
+        if validate_files:
+            image_paths = self._validate_image_paths(image_paths)
+        if len(image_paths) == 0:
+            raise ValueError("No valid image paths found")
+        # CPU decode (as in the reference), then same-sized frames go to the GPU together: resize + crop +
+        # normalise + encode run in HBM.  Unreadable / too-small images are dropped (n may be < len(paths)).
+        decoded = []
+        for p in image_paths:
+            try:
+                im = self._load_and_validate_image(p)
+                if im is not None:
+                    decoded.append(np.asarray(im))
+            except Exception as e:
+                self.logger.warning("Failed to load image", path=p, error=str(e))
+        if not decoded:
+            raise RuntimeError("No images were successfully encoded")
+        out = np.empty((len(decoded), self.vision_model.embed_dim), dtype=np.float32)
+        by_shape: Dict[Tuple[int, int], List[int]] = {}
+        for i, a in enumerate(decoded):
+            by_shape.setdefault(a.shape[:2], []).append(i)
+        with self._lock:
+            for (h, w), idxs in by_shape.items():
+                batch = np.stack([decoded[i] for i in idxs])
+                mode = "identity" if (h, w) == (self.vision_config.image,) * 2 else "shortest_edge_crop"
+                emb = self.vision_model.encode_frames(batch, mode, C.CLIP_MEAN, C.CLIP_STD, normalize=True)
+                out[idxs] = emb.cpu().numpy()
+        return out
+
+    def encode_frames(self, frames_u8, mode="identity", bgr=False):
+        """Device path without files: uint8 [n,h,w,3] -> float32 CUDA [n,D], rows L2-normalised."""
+        with self._lock:
+            return self.vision_model.encode_frames(frames_u8, mode, C.CLIP_MEAN, C.CLIP_STD, bgr=bgr, normalize=True)
+
+    def extract_features_batch(self, keyframe_folder: str):
+        """core.py:1643: walk <root>/<folder>/*.jpg|png -> (features [N,D], [KeyframeMetadata])."""
+        paths, metas = [], []
+        for folder in sorted(os.listdir(keyframe_folder)):
+            fdir = os.path.join(keyframe_folder, folder)
+            if not os.path.isdir(fdir):
+                continue
+            names = sorted((n for n in os.listdir(fdir) if n.lower().endswith((".jpg", ".jpeg", ".png"))),
+                           key=lambda n: (_frame_id_of(n), n))
+            for pos, n in enumerate(names):
+                paths.append(os.path.join(fdir, n))
+                metas.append(KeyframeMetadata(folder_name=folder, image_name=n, frame_id=_frame_id_of(n),
+                                              file_path=os.path.join(fdir, n), sequence_position=pos,
+                                              total_frames=len(names)))
+        if not paths:
+            raise ValueError(f"No keyframes found in {keyframe_folder}")
+        feats = self.encode_images(paths, validate_files=False, show_progress=False)
+        if len(feats) != len(metas):
+            raise RuntimeError("some keyframes could not be decoded; features and metadata would be misaligned")
+        for m, f in zip(metas, feats):
+            m.clip_features = f                            # core.py:1737-1738
+        return feats, metas
+
+
+# ----------------------------------------------------------------------------------------------
+# FAISSRetriever (legacy index, core.py:687)
+# ----------------------------------------------------------------------------------------------
+class FAISSRetriever:
+    def __init__(self, config=None, logger=None, cache=None):
+        self.config = config
+        self.logger = logger or _NullLogger()
+        self.index = None
+        self.index_type = "IndexFlatIP"       # every configured type is coerced to exact IP (core.py:1205-1219)
+        self.use_gpu = True
+        self.dimension = None
+        self.is_trained = False
+        self.id_to_metadata = {}
+        self.metadata_to_id = {}
+        self.next_id = 0
+        self._lock = threading.RLock()
+
+    def _calculate_proper_similarity(self, query_vec, target_vec):
+        """core.py:736-756, host side: k x d flops per search."""
+        if target_vec is None:
+            return 0.0
+        dot = np.dot(query_vec, target_vec)
+        qn, tn = np.linalg.norm(query_vec), np.linalg.norm(target_vec)
+        if qn == 0 or tn == 0:
+            return 0.0
+        return max(0.0, min(1.0, dot / (qn * tn)))
+
+    def _normalize_and_validate_features(self, features):
+        """core.py:1176-1196 with the arithmetic in HBM; returns a float32 CUDA tensor."""
+        if not isinstance(features, np.ndarray):
+            raise ValueError("Features must be numpy array")
+        if features.size == 0:
+            raise ValueError("Features array is empty")
+        if features.ndim == 1:
+            features = features.reshape(1, -1)
+        elif features.ndim != 2:
+            raise ValueError(f"Features must be 1D or 2D, got {features.ndim}D")
+        t = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).cuda()
+        if count_nonfinite_and_normalize(t) != 0:
+            raise ValueError("Features contain NaN or infinite values")
+        return t
+
+    def build_index(self, features, metadata_list, index_type=None, validate_consistency=True) -> None:
+        if len(features) != len(metadata_list):
+            raise ValueError(f"Features count ({len(features)}) != metadata count ({len(metadata_list)})")
+        if len(features) == 0:
+            raise ValueError("Cannot build index from empty feature set")
+        with self._lock:
+            self.id_to_metadata, self.metadata_to_id = {}, {}
+            for i, m in enumerate(metadata_list):
+                try:
+                    m._validate()
+                except Exception as e:
+                    raise ValueError(f"Invalid metadata at index {i}: {e}")
+                key = m.get_unique_key()
+                if validate_consistency and key in self.metadata_to_id:
+                    raise ValueError(f"Duplicate metadata key found: {key}")
+                self.id_to_metadata[i] = m
+                self.metadata_to_id[key] = i
+            self.next_id = len(metadata_list)
+            t = self._normalize_and_validate_features(features)
+            self.dimension = t.shape[1]
+            try:
+                self.index = FlatIPIndex(self.dimension, capacity=t.shape[0])
+                self.index.add(t)
+                self.is_trained = True
+            except Exception as e:
+                raise RuntimeError(f"Failed to add vectors to index: {e}")
+            if validate_consistency and self.index.ntotal != len(self.id_to_metadata):
+                raise RuntimeError("Index validation failed: index size != metadata count")
+
+    def search(self, query_features, k: int = 50, search_params=None, validate_results=True) -> List[SearchResult]:
+        if not self.is_trained or not self.index:
+            raise RuntimeError("Index not trained. Call build_index first.")
+        if len(self.id_to_metadata) == 0:
+            return []
+        with self._lock:
+            q = self._normalize_and_validate_features(query_features)
+            if q.shape[1] != self.dimension:
+                raise ValueError(f"Query dimension ({q.shape[1]}) != index dimension ({self.dimension})")
+            if search_params:
+                for param, value in search_params.items():
+                    if hasattr(self.index, param):
+                        setattr(self.index, param, value)
+            try:
+                D, I = self.index.search_device(q, k)
+                similarities, indices = D.cpu().numpy(), I.cpu().numpy()
+            except Exception as e:
+                raise RuntimeError(f"Search operation failed: {e}")
+            qn = q.cpu().numpy()
+            results = []
+            for i, (sims, idxs) in enumerate(zip(similarities, indices)):
+                for rank, (_, idx) in enumerate(zip(sims, idxs)):
+                    idx = int(idx)
+                    if idx >= 0 and idx in self.id_to_metadata:
+                        md = self.id_to_metadata[idx]
+                        if validate_results:
+                            try:
+                                md._validate()
+                            except Exception:
+                                continue
+                        s = self._calculate_proper_similarity(qn[i], md.clip_features)
+                        results.append(SearchResult(metadata=md, similarity_score=s, rank=rank + 1, query_relevance=s))
+            return results
+
+    def search_by_id(self, metadata_key: str, k: int = 10):
+        if metadata_key not in self.metadata_to_id:
+            return []
+        md = self.id_to_metadata.get(self.metadata_to_id[metadata_key])
+        if md is None or md.clip_features is None:
+            return []
+        return self.search(md.clip_features, k)
+
+
+# ----------------------------------------------------------------------------------------------
+# UnifiedIndex (unified_index.py:63) - build / load / search_vectors, container out of scope
+# ----------------------------------------------------------------------------------------------
+class UnifiedIndex:
+    def __init__(self, config=None, logger=None):
+        self.config = config
+        self.logger = logger
+        self.lock = threading.RLock()
+        self.is_loaded = False
+        self.faiss_index = None
+        self.metadata_list: List[Dict[str, Any]] = []
+        self.metadata_cache: Dict[int, Dict[str, Any]] = {}
+        self.vectors = None
+        self.index_file = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def close(self):
+        if self.faiss_index is not None:
+            self.faiss_index.close()
+        self.faiss_index, self.is_loaded = None, False
+
+    def _scan_files(self, keyframes_dir):
+        found = []
+        for root, _, files in os.walk(keyframes_dir):
+            for n in files:
+                if n.lower().endswith(".jpg"):
+                    found.append(os.path.join(root, n))
+        return sorted(found)                                # deterministic row order (hard part 7)
+
+    def create_unified_index(self, keyframes_dir, clip_processor, output_file, csv_mappings=None, progress_callback=None,
+                             resume_from_existing=False, chunk_size=1000):
+        """unified_index.py:94 with the batch-1 thread pool (:759-812) replaced by whole-chunk GPU batches
+        (SURVEY.md section 8f rank 1).  Returns the same stats keys (:127-138)."""
+        t0 = time.time()
+        stats = {"total_files": 0, "processed_files": 0, "skipped_files": 0, "failed_files": 0, "build_time": 0.0,
+                 "file_size_mb": 0.0, "vectors_count": 0, "thumbnails_count": 0, "full_images_count": 0,
+                 "resumed": False, "chunks_processed": 0}
+        files = self._scan_files(keyframes_dir)
+        stats["total_files"] = len(files)
+        vecs, metas = [], []
+        for c0 in range(0, len(files), chunk_size):
+            chunk = files[c0:c0 + chunk_size]
+            try:
+                feats = clip_processor.encode_images(chunk, validate_files=False, show_progress=False)
+                if len(feats) != len(chunk):
+                    raise RuntimeError("dropped images")
+                kept = chunk
+            except Exception:                                # fall back to per-file calls to find the bad ones
+                feats, kept = [], []
+                for p in chunk:
+                    try:
+                        feats.append(clip_processor.encode_images([p], validate_files=False, show_progress=False)[0])
+                        kept.append(p)
+                    except Exception:
+                        stats["failed_files"] += 1
+                feats = np.stack(feats) if feats else np.zeros((0, 1), np.float32)
+            for p, f in zip(kept, feats):
+                rel = os.path.relpath(p, keyframes_dir)
+                folder = os.path.dirname(rel) or os.path.basename(os.path.normpath(keyframes_dir))
+                metas.append({"folder_name": folder, "image_name": os.path.basename(p), "frame_id": _frame_id_of(p),
+                              "file_path": p, "vector_index": len(metas)})
+                vecs.append(f)
+            stats["processed_files"] += len(kept)
+            stats["chunks_processed"] += 1
+            if progress_callback:
+                progress_callback(stats["processed_files"], len(files))
+        V = np.stack(vecs).astype(np.float32) if vecs else np.zeros((0, 1), np.float32)
+        np.savez(output_file if output_file.endswith(".npz") else output_file + ".npz", vectors=V,
+                 metadata=np.frombuffer(json.dumps(metas).encode(), dtype=np.uint8),
+                 csv_mappings=np.frombuffer(json.dumps(csv_mappings or {}).encode(), dtype=np.uint8))
+        out = output_file if output_file.endswith(".npz") else output_file + ".npz"
+        stats["vectors_count"] = len(V)
+        stats["file_size_mb"] = os.path.getsize(out) / 1e6
+        stats["build_time"] = time.time() - t0
+        self._install(V, metas, out)
+        return stats
+
+    build_index = create_unified_index                      # README.md:124-136 alias
+
+    def _install(self, V, metas, path):
+        with self.lock:
+            self.vectors = V
+            self.metadata_list = metas
+            self.metadata_cache = {}
+            if self.faiss_index is not None:
+                self.faiss_index.close()
+            self.faiss_index = FlatIPIndex(V.shape[1] if V.size else 1, capacity=len(V))
+            if len(V):
+                # unified_index.py:1770-1779: normalize_L2 then add, here fused in the append kernel
+                self.faiss_index.add(V, normalize=True)
+            self.index_file = path
+            self.is_loaded = True
+
+    def load_unified_index(self, index_file):
+        path = index_file if index_file.endswith(".npz") else index_file + ".npz"
+        z = np.load(path, allow_pickle=False)
+        metas = json.loads(bytes(z["metadata"]).decode())
+        self._install(z["vectors"], metas, path)
+        return {"vectors_count": len(self.vectors), "metadata_count": len(metas), "index_file": path}
+
+    def _get_metadata_cached(self, idx):
+        idx = int(idx)
+        if 0 <= idx < len(self.metadata_list):
+            return self.metadata_list[idx]
+        return None
+
+    def search_vectors(self, query_vector, k: int = 50, filter_func: Callable = None) -> List[Dict[str, Any]]:
+        """unified_index.py:480-538: 0-based rank, similarity_score = 1 - inner product."""
+        if not self.is_loaded:
+            raise ValueError("Index not loaded. Call load_unified_index() first.")
+        distances, indices = self.faiss_index.search(np.asarray(query_vector, dtype=np.float32).reshape(1, -1), k)
+        results = []
+        for i, (dist, idx) in enumerate(zip(distances[0], indices[0])):
+            if idx == -1:
+                break
+            md = self._get_metadata_cached(idx)
+            if md is None:
+                continue
+            if filter_func and not filter_func(md):
+                continue
+            results.append({"rank": i, "similarity_score": float(1.0 - dist), "metadata": md, "index": int(idx)})
+        return results
+
+    def augmented_search(self, query, top_k=10, clip_processor=None):
+        """README.md:152-158 alias: text (needs clip_processor) or vector query -> search_vectors."""
+        if isinstance(query, str):
+            if clip_processor is None:
+                raise ValueError("augmented_search(text) needs clip_processor=")
+            query = clip_processor.encode_text(query)[0]
+        return self.search_vectors(np.asarray(query), k=top_k)
+
+    def get_temporal_context(self, frame_index, window_size=3):
+        return []                                            # always empty in the reference (unified_index.py:1221-1224)
+
+
+def create_optimized_index(keyframes_dir, clip_processor, output_file, **kw):      # unified_index.py:1889
+    ui = UnifiedIndex()
+    return ui, ui.create_unified_index(keyframes_dir, clip_processor, output_file, **kw)
+
+
+def load_optimized_index(index_file):                                               # unified_index.py:1922
+    ui = UnifiedIndex()
+    ui.load_unified_index(index_file)
+    return ui
+
+
+class UnifiedBuilderIntegration:
+    """unified_builder.py:26: forwards build / load / search for an object holding `.clip_processor`."""
+
+    def __init__(self, system):
+        self.system = system
+        self.unified_index: Optional[UnifiedIndex] = None
+
+    def create_unified_index_fast(self, keyframes_dir, output_file, progress_callback=None, **kw):
+        self.unified_index, stats = create_optimized_index(keyframes_dir, self.system.clip_processor, output_file,
+                                                           progress_callback=progress_callback, **kw)
+        return stats
+
+    def load_unified_index_fast(self, index_file):
+        self.unified_index = load_optimized_index(index_file)
+        return True
+
+    def search_unified_fast(self, query_vector, k: int = 50, similarity_threshold: float = 0.0):
+        if not self.unified_index:
+            raise ValueError("Unified index not loaded. Call load_unified_index_fast() first.")
+        out = []
+        for r in self.unified_index.search_vectors(query_vector, k=k, filter_func=lambda meta: True):
+            if r["similarity_score"] >= similarity_threshold:          # unified_builder.py:229
+                md = r["metadata"]
+                legacy = KeyframeMetadata(folder_name=md["folder_name"], image_name=md["image_name"],
+                                          frame_id=int(md["frame_id"]), file_path=md["file_path"])
+                out.append({"metadata": legacy, "similarity_score": r["similarity_score"], "rank": r["rank"],
+                            "temporal_context": self.unified_index.get_temporal_context(r["index"], 3),
+                            "index": r["index"]})
+        return out
+
+
+def add_unified_index_support(system):                                              # unified_builder.py:427
+    system.unified_builder = UnifiedBuilderIntegration(system)
+    return system.unified_builder
+
+
+class RAGBuilder:                                                                    # README.md:124-136
+    def __init__(self, clip_processor):
+        self.clip_processor = clip_processor
+
+    def build_index(self, keyframes_dir, output_file="index.npz"):
+        return create_optimized_index(keyframes_dir, self.clip_processor, output_file)[0]
+
+
+class RAGRetriever:                                                                  # README.md:152-158
+    def __init__(self, index: UnifiedIndex, clip_processor):
+        self.index, self.clip_processor = index, clip_processor
+
+    def search(self, text, top_k=10):
+        return self.index.augmented_search(text, top_k=top_k, clip_processor=self.clip_processor)
+
+
+# ----------------------------------------------------------------------------------------------
+# video_frame_filter.py
+# ----------------------------------------------------------------------------------------------
+SIM_THRESHOLD = 0.98       # video_frame_filter.py:16
+FRAME_SIZE = (224, 224)
+
+
+class FrameFilter:
+    """DINO ViT-S/16 CLS embedding + keep-if-cos<0.98-vs-last-kept, entirely in HBM (README alias of
+    video_frame_filter.extract_unique_frames)."""
+
+    def __init__(self, weights=None, mean=C.IMAGENET_MEAN, std=C.IMAGENET_STD, max_batch=256, compute="bf16", seed=0,
+                 threshold=SIM_THRESHOLD):
+        cfg = C.DINO_VIT_S16
+        w = make_weights(cfg, seed) if weights is None else (
+            from_hf_state_dict(cfg, weights) if any(k.startswith("embeddings.") for k in weights) else weights)
+        self.tower = Tower(cfg, w, max_batch=max_batch, compute=compute)
+        self.mean, self.std, self.threshold = mean, std, threshold
+        self.state = DedupState(cfg.width)
+
+    def extract_embedding(self, image) -> np.ndarray:
+        """video_frame_filter.py:28: PIL image (already 224x224 RGB) -> CLS embedding [384] (not normalised)."""
+        a = np.asarray(image.convert("RGB"))[None]
+        mode = "identity" if a.shape[1:3] == (224, 224) else "stretch"
+        return self.tower.encode_frames(a, mode, self.mean, self.std, normalize=False)[0].cpu().numpy()
+
+    def filter_frames(self, frames_bgr, reset=True):
+        """uint8 BGR frames [n,h,w,3] in decode order -> bool keep mask (video_frame_filter.py:58-70 for a batch)."""
+        if reset:
+            self.state.reset()
+        keep = []
+        for i in range(0, len(frames_bgr), self.tower.max_batch):
+            emb = self.tower.encode_frames(frames_bgr[i:i + self.tower.max_batch], "stretch", self.mean, self.std, bgr=True,
+                                           normalize=False)
+            keep.append(self.state.keep_mask(emb, self.threshold))
+        return torch.cat(keep).cpu().numpy().astype(bool) if keep else np.zeros(0, bool)
+
+    def extract_frames(self, video_path, keyframe_root="keyframes", map_root="map", batch=64):
+        return extract_unique_frames(video_path, keyframe_root, map_root, frame_filter=self, batch=batch)
+
+    def apply_filters(self, frames_bgr):
+        return [f for f, k in zip(frames_bgr, self.filter_frames(np.asarray(frames_bgr))) if k]
+
+
+_default_filter = None
+
+
+def _filter():
+    global _default_filter
+    if _default_filter is None:
+        _default_filter = FrameFilter()
+    return _default_filter
+
+
+def extract_embedding(image):                                                         # video_frame_filter.py:28
+    return _filter().extract_embedding(image)
+
+
+def extract_unique_frames(video_path, keyframe_root, map_root, frame_filter=None, batch=64):
+    """video_frame_filter.py:35: decode with cv2 (CPU, as in the reference), embed + dedup on the GPU in batches,
+    write kept frames as <count>.jpg and the CSV map (n, pts_time, fps, frame_idx as ints).  Returns #saved."""
+    try:
+        import cv2
+    except ImportError as e:
+        raise RuntimeError("extract_unique_frames needs OpenCV for video decode (cv2 is not installed); "
+                           "use FrameFilter.filter_frames(frames) on decoded frames instead") from e
+    ff = frame_filter or _filter()
+    ff.state.reset()
+    cap = cv2.VideoCapture(video_path)
+    name = os.path.splitext(os.path.basename(video_path))[0]
+    out_dir = os.path.join(keyframe_root, name)
+    os.makedirs(out_dir, exist_ok=True)
+    os.makedirs(map_root, exist_ok=True)
+    fps = cap.get(cv2.CAP_PROP_FPS)
+    count = saved = 0
+    with open(os.path.join(map_root, f"{name}.csv"), "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["n", "pts_time", "fps", "frame_idx"])
+        buf, pts = [], []
+
+        def flush():
+            nonlocal saved, count
+            if not buf:
+                return
+            keep = ff.filter_frames(np.stack(buf), reset=False)
+            for fr, t, k in zip(buf, pts, keep):
+                if k:
+                    cv2.imwrite(os.path.join(out_dir, f"{count}.jpg"), fr)
+                    wr.writerow([int(saved), int(t), int(fps), int(count)])
+                    saved += 1
+                count += 1
+            buf.clear()
+            pts.clear()
+
+        while cap.isOpened():
+            ret, frame = cap.read()
+            if not ret:
+                break
+            buf.append(frame)
+            pts.append(cap.get(cv2.CAP_PROP_POS_MSEC) / 1000.0)
+            if len(buf) == batch:
+                flush()
+        flush()
+    cap.release()
+    return saved

