@@ -12,10 +12,10 @@
 //   The MFMA is issued with W as the A operand and X as the B operand, so a lane ends up holding
 //   4 consecutive n of one row m: bias/activation/residual epilogues are float4-wide and the
 //   residual stream is updated in place.
-//   Staging is register-split (issue the next tile's 16-byte full-line loads, compute the current
-//   tile from LDS, then write the registers to the other LDS buffer; one barrier per K step).
-//   LDS rows are 128 bytes; 16-byte chunk c of row r sits at chunk (c ^ (r & 7)), which makes both the
-//   ds_write_b128 of whole rows and the ds_read_b128 of MFMA fragments bank-conflict free.
+//   Staging is LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 full 128-byte rows per wave instruction) into two
+//   LDS buffers: the next tile's DMA is in flight under the current tile's MFMAs, one barrier per K step.
+//   LDS rows are 128 bytes; 16-byte chunk c of row r sits at chunk position (c ^ (r & 7)) - applied on the DMA
+//   source address and on the fragment read - which makes the ds_read_b128 of MFMA fragments bank-conflict free.
 //   Workgroup ids are remapped so that the tiles sharing an X row panel run on one XCD (one L2).
 #include "tower.h"
 #include "tower_kernels.h"
@@ -181,7 +181,7 @@ __device__ __forceinline__ void mma_chunk<float>(const uint4 &w, const uint4 &x,
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -199,17 +199,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     constexpr int EPR = ROWB / (int)sizeof(T);   // elements of K per step
     const int KT = g.K / EPR;
 
-    // staging assignment: 16 slots of 8 rows per operand; wave w owns slots 4w..4w+3
+    // staging: LDS-DMA (global_load_lds_dwordx4).  One wave instruction fills 8 rows x 128 B = 1 KiB: lane l lands
+    // at (wave-uniform base) + 16*l, i.e. row 8i + (l >> 3), chunk position l & 7.  The XOR swizzle therefore goes
+    // on the SOURCE: the lane fetches logical chunk (l & 7) ^ (row & 7) of its row, and fragment reads apply the
+    // same involution.  16 such pieces per operand per K step; wave w issues pieces 4w .. 4w+3 of X and of W.
     const unsigned char *srcX[4], *srcW[4];
-    int dst[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int r = 8 * (wave * 4 + j) + (lane >> 3), c = lane & 7;
+        const int r = 8 * (wave * 4 + j) + (lane >> 3), c = (lane & 7) ^ (lane >> 3);
         const int xm = min(m0 + r, g.M - 1), wr = min(n0 + r, g.N - 1);
         srcX[j] = reinterpret_cast<const unsigned char *>(g.A) + ((int64_t)xm * g.lda) * sizeof(T) + c * 16;
         srcW[j] = reinterpret_cast<const unsigned char *>(g.W) + ((int64_t)wr * g.ldw) * sizeof(T) + c * 16;
-        dst[j] = r * ROWB + ((c ^ (r & 7)) << 4);
     }
+    auto stage = [&](int kt, int buf) {
+        unsigned char *base = smem + buf * 2 * TILE_BYTES + (wave * 4) * 1024;
+        const int64_t adv = (int64_t)kt * ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcX[j] + adv),
+                                             (__attribute__((address_space(3))) void *)(base + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcW[j] + adv),
+                                             (__attribute__((address_space(3))) void *)(base + TILE_BYTES + j * 1024), 16, 0, 0);
+        }
+    };
     // fragment read offsets inside a 16-row tile for the two 64-byte halves of a row
     int foff[2];
 #pragma unroll
@@ -221,30 +233,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 rx[4], rw[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        rx[j] = *reinterpret_cast<const uint4 *>(srcX[j]);
-        rw[j] = *reinterpret_cast<const uint4 *>(srcW[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<uint4 *>(smem + dst[j]) = rx[j];
-        *reinterpret_cast<uint4 *>(smem + TILE_BYTES + dst[j]) = rw[j];
-    }
-    __syncthreads();
-
+    stage(0, 0);
     for (int kt = 0; kt < KT; ++kt) {
-        unsigned char *cur = smem + (kt & 1) * 2 * TILE_BYTES;
-        unsigned char *nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-        // unconditional prefetch (the last trip re-loads the last tile into the idle buffer): keeping the staging
-        // registers out of any branch lets them stay in VGPRs and the loads stay in flight under the MFMAs
-        const int64_t adv = (int64_t)min(kt + 1, KT - 1) * ROWB;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            rx[j] = *reinterpret_cast<const uint4 *>(srcX[j] + adv);
-            rw[j] = *reinterpret_cast<const uint4 *>(srcW[j] + adv);
-        }
+        // tile kt has landed for every wave, and every wave is done reading the other buffer (tile kt-1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);          // in flight under this tile's MFMAs
+        const unsigned char *cur = smem + (kt & 1) * 2 * TILE_BYTES;
         const unsigned char *xs = cur + (wm * 64) * ROWB, *ws = cur + TILE_BYTES + (wn * 64) * ROWB;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -259,55 +254,71 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(wf[nt], xf[mt], acc[nt][mt]);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<uint4 *>(nxt + dst[j]) = rx[j];
-            *reinterpret_cast<uint4 *>(nxt + TILE_BYTES + dst[j]) = rw[j];
-        }
-        __syncthreads();
     }
 
-    // epilogue: lane holds C[m][n..n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4)
+    // epilogue: lane holds C[m][n..n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4).
+    // All global reads of the epilogue (bias, residual, position rows) are issued back to back before the first use so
+    // that their latency is paid once per tile, not once per fragment.
+    int mrow[4], ncol[4];
+    bool mok[4], nok[4];
+    float4 bv[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + (lane & 15);
-        if (m >= g.M) continue;
+    for (int t = 0; t < 4; ++t) {
+        mrow[t] = m0 + wm * 64 + t * 16 + (lane & 15);
+        ncol[t] = n0 + wn * 64 + t * 16 + 4 * (lane >> 4);
+        mok[t] = mrow[t] < g.M;
+        nok[t] = ncol[t] < g.N;
+        mrow[t] = min(mrow[t], g.M - 1);
+        ncol[t] = min(ncol[t], g.N - 4);
+        bv[t] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + ncol[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (EPI == EPI_RESID || EPI == EPI_PATCH) {
+        float4 rv[4][4];
+        float *rowp[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
-            if (n >= g.N) continue;
-            float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
-            if (g.bias) {
-                const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n);
-                v[0] += bv.x;
-                v[1] += bv.y;
-                v[2] += bv.z;
-                v[3] += bv.w;
-            }
-            if (EPI == EPI_STORE) {
-                if (g.act >= 0) {
+        for (int mt = 0; mt < 4; ++mt) {
+            if (EPI == EPI_RESID) {
+                rowp[mt] = g.resid + (int64_t)mrow[mt] * g.ldr;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = act_fn(v[i], g.act);
-                }
-                El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)m * g.ldo + n, v);
-            } else if (EPI == EPI_RESID) {
-                float4 *p = reinterpret_cast<float4 *>(g.resid + (int64_t)m * g.ldr + n);
-                float4 r = *p;
-                r.x += v[0];
-                r.y += v[1];
-                r.z += v[2];
-                r.w += v[3];
-                *p = r;
-            } else if (EPI == EPI_PATCH) {
-                const int img = m / g.G2, pch = m % g.G2;
-                const float4 pv = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + n);
-                float4 r = make_float4(v[0] + pv.x, v[1] + pv.y, v[2] + pv.z, v[3] + pv.w);
-                *reinterpret_cast<float4 *>(g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr + n) = r;
-            } else {   // EPI_F32
-                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)m * g.ldo + n) =
-                    make_float4(v[0], v[1], v[2], v[3]);
+                for (int nt = 0; nt < 4; ++nt) rv[mt][nt] = *reinterpret_cast<const float4 *>(rowp[mt] + ncol[nt]);
+            } else {
+                const int img = mrow[mt] / g.G2, pch = mrow[mt] % g.G2;
+                rowp[mt] = g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    rv[mt][nt] = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol[nt]);
             }
         }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float4 r = rv[mt][nt];
+                r.x += acc[nt][mt][0] + bv[nt].x;
+                r.y += acc[nt][mt][1] + bv[nt].y;
+                r.z += acc[nt][mt][2] + bv[nt].z;
+                r.w += acc[nt][mt][3] + bv[nt].w;
+                if (mok[mt] && nok[nt]) *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
+            }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float v[4] = {acc[nt][mt][0] + bv[nt].x, acc[nt][mt][1] + bv[nt].y, acc[nt][mt][2] + bv[nt].z,
+                              acc[nt][mt][3] + bv[nt].w};
+                if (ACT >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = act_fn(v[i], ACT);
+                }
+                if (mok[mt] && nok[nt]) {
+                    if (EPI == EPI_STORE)
+                        El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt], v);
+                    else   // EPI_F32
+                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt]) =
+                            make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
     }
 }
 
@@ -407,17 +418,17 @@ __global__ __launch_bounds__(512) void attention_kernel(const T *__restrict__ qk
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int ACT>
 int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
     static bool attr_done = false;
     if (!attr_done) {
-        IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    GEMM_LDS));
+        IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<T, EPI, ACT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
         attr_done = true;
     }
     IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
-    hipLaunchKernelGGL((gemm_kernel<T, EPI>), dim3(MT * NT), dim3(256), GEMM_LDS, s, g);
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, ACT>), dim3(MT * NT), dim3(256), GEMM_LDS, s, g);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
@@ -425,10 +436,13 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
 template <typename T>
 int launch_gemm_e(int epi, const GemmArgs &g, hipStream_t s) {
     switch (epi) {
-        case EPI_STORE: return launch_gemm_t<T, EPI_STORE>(g, s);
-        case EPI_RESID: return launch_gemm_t<T, EPI_RESID>(g, s);
-        case EPI_PATCH: return launch_gemm_t<T, EPI_PATCH>(g, s);
-        default: return launch_gemm_t<T, EPI_F32>(g, s);
+        case EPI_STORE:
+            if (g.act == IVR_ACT_QUICK_GELU) return launch_gemm_t<T, EPI_STORE, IVR_ACT_QUICK_GELU>(g, s);
+            if (g.act == IVR_ACT_GELU_ERF) return launch_gemm_t<T, EPI_STORE, IVR_ACT_GELU_ERF>(g, s);
+            return launch_gemm_t<T, EPI_STORE, -1>(g, s);
+        case EPI_RESID: return launch_gemm_t<T, EPI_RESID, -1>(g, s);
+        case EPI_PATCH: return launch_gemm_t<T, EPI_PATCH, -1>(g, s);
+        default: return launch_gemm_t<T, EPI_F32, -1>(g, s);
     }
 }
 

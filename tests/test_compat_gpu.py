@@ -136,9 +136,9 @@ def test_unified_index_build_load_search(extractor, keyframes, tmp_path):
     with pytest.raises(ValueError):
         ub.search_unified_fast(q)
     ub.load_unified_index_fast(str(tmp_path / "idx"))
-    thr = want[3][1]
+    thr = 0.5 * (want[2][1] + want[3][1])              # between two hits: no float tie at the cut
     fast = ub.search_unified_fast(q, k=10, similarity_threshold=thr)
-    assert [r["index"] for r in fast] == [i for _, s, i in want if s >= thr - 2e-5][:len(fast)]
+    assert [r["index"] for r in fast] == [i for _, s, i in want if s >= thr]
     assert fast[0]["metadata"].folder_name and fast[0]["temporal_context"] == []
     rr = RAGRetriever(ui, extractor).search("a red car", top_k=3)
     assert len(rr) == 3
