@@ -29,7 +29,7 @@ template <typename T>
 struct El;
 template <>
 struct El<unsigned short> {
-    static constexpr int per16 = 8;   // elements per 16 bytes
+    static constexpr int per16 = 8;   // elements per 16 bytes (attention_kernel chunking)
     static __device__ __forceinline__ void unpack(const uint4 &u, float (&f)[8]) {
         f[0] = __uint_as_float(u.x << 16);
         f[1] = __uint_as_float(u.x & 0xffff0000u);
@@ -418,6 +418,164 @@ __global__ __launch_bounds__(512) void attention_kernel(const T *__restrict__ qk
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 attention on MFMA (production path): one wave per (image, head, 64-query block), flash-style loop
+// over 64-key blocks.  Both products are issued transposed so that the query index stays on the lane:
+//   S^T[key][query] = K Q^T      A = K rows, B = Q rows          -> lane holds 16 keys of ONE query per query tile
+//   O^T[dh][query]  = V^T P^T    A = V^T rows (LDS), B = P^T     -> the softmax'd accumulator IS the B operand
+// The k order of the second product is permuted (element j of lane group g = key 16*(2ks + (j>>2)) + 4g + (j&3)) so
+// that P goes from accumulator registers to operand registers with a bf16 pack and no cross-lane traffic; V^T is
+// staged per wave in LDS (rows padded to 136 B: conflict-free ds_read_b64) with the same permutation on the read.
+// Row max / sum across the 4 lanes of a query are two wave shuffles; the online-softmax rescale is lane-local.
+// ---------------------------------------------------------------------------------------------
+constexpr int VT_STRIDE = 136;                    // bytes per V^T row (64 keys * 2 B + 8 B pad)
+constexpr int VT_BYTES = 64 * VT_STRIDE;          // per wave
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned short *__restrict__ qkv, unsigned short *__restrict__ att,
+                                                             int n, int Tn, int D, int heads, int causal) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nqb = (Tn + 63) >> 6;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= (int64_t)n * heads * nqb) return;          // no workgroup barrier below: waves are independent
+    const int qb = (int)(item % nqb);
+    const int h = (int)((item / nqb) % heads);
+    const int img = (int)(item / ((int64_t)nqb * heads));
+    unsigned char *vt = smem + wave * VT_BYTES;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t rs = 3 * (int64_t)D;                     // qkv row stride (elements)
+    const unsigned short *base = qkv + (int64_t)img * Tn * rs + h * 64;
+
+    // Q fragments (B operand of S^T): query = qb*64 + 16*qt + c, dh = 32*ks + 8*g .. +7
+    uint4 qf[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = min(qb * 64 + qt * 16 + c, Tn - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks][qt] = *reinterpret_cast<const uint4 *>(base + q * rs + ks * 32 + g * 8);
+    }
+    f32x4 o[4][4];        // [dh tile][query tile]: O^T[16*nt + 4g + r][16*qt + c]
+    float m[4], l[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        m[a] = -INFINITY;
+        l[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) o[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int kend = causal ? min(Tn, qb * 64 + 64) : Tn;
+    for (int k0 = 0; k0 < kend; k0 += 64) {
+        // ---- S^T block = K Q^T
+        f32x4 s[4][4];    // [key tile][query tile]: key = k0 + 16*kt + 4g + r, query = 16*qt + c
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int key = min(k0 + kt * 16 + c, Tn - 1);
+            uint4 kf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[ks] = *reinterpret_cast<const uint4 *>(base + D + key * rs + ks * 32 + g * 8);
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[0]), __builtin_bit_cast(bf16x8_t, qf[0][qt]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[1]), __builtin_bit_cast(bf16x8_t, qf[1][qt]), acc, 0, 0, 0);
+                s[kt][qt] = acc;
+            }
+        }
+        // ---- V^T block -> LDS: lane owns key k0 + lane, scatters its 64 dh values down a column
+        {
+            const int key = min(k0 + lane, Tn - 1);
+            const uint4 *vp = reinterpret_cast<const uint4 *>(base + 2 * D + key * rs);
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const uint4 v = vp[ch];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    *reinterpret_cast<unsigned short *>(vt + (ch * 8 + 2 * i) * VT_STRIDE + lane * 2) = (unsigned short)(w[i] & 0xffffu);
+                    *reinterpret_cast<unsigned short *>(vt + (ch * 8 + 2 * i + 1) * VT_STRIDE + lane * 2) = (unsigned short)(w[i] >> 16);
+                }
+            }
+        }
+        // ---- masks + online softmax (per query column: 16 values in this lane, 4 lanes per query)
+        uint4 pf[2][4];   // P^T fragments (B operand of O^T), k-step ks covers key tiles 2ks, 2ks+1
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            const int q = qb * 64 + qt * 16 + c;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + g * 4 + r;
+                    if (key >= Tn || (causal && key > q)) s[kt][qt][r] = -INFINITY;
+                    mx = fmaxf(mx, s[kt][qt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[qt], mx);
+            // mn stays -inf only for a query that has seen no valid key yet (cannot happen: key 0 is always visible)
+            const float alpha = (m[qt] == -INFINITY) ? 0.f : __expf(m[qt] - mn);
+            m[qt] = mn;
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = (s[kt][qt][r] == -INFINITY) ? 0.f : __expf(s[kt][qt][r] - mn);
+                    s[kt][qt][r] = p;
+                    sum += p;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            l[qt] = l[qt] * alpha + sum;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                o[nt][qt][0] *= alpha;
+                o[nt][qt][1] *= alpha;
+                o[nt][qt][2] *= alpha;
+                o[nt][qt][3] *= alpha;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 f;
+                f.x = ivr_f32_to_bf16(s[2 * ks][qt][0]) | ((uint32_t)ivr_f32_to_bf16(s[2 * ks][qt][1]) << 16);
+                f.y = ivr_f32_to_bf16(s[2 * ks][qt][2]) | ((uint32_t)ivr_f32_to_bf16(s[2 * ks][qt][3]) << 16);
+                f.z = ivr_f32_to_bf16(s[2 * ks + 1][qt][0]) | ((uint32_t)ivr_f32_to_bf16(s[2 * ks + 1][qt][1]) << 16);
+                f.w = ivr_f32_to_bf16(s[2 * ks + 1][qt][2]) | ((uint32_t)ivr_f32_to_bf16(s[2 * ks + 1][qt][3]) << 16);
+                pf[ks][qt] = f;
+            }
+        }
+        // ---- O^T += V^T P^T   (the wave's own LDS writes above are complete before these reads: same wave, lgkmcnt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char *row = vt + (nt * 16 + c) * VT_STRIDE + ks * 64 + g * 8;
+                const uint2 lo = *reinterpret_cast<const uint2 *>(row), hi = *reinterpret_cast<const uint2 *>(row + 32);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt)
+                    o[nt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[ks][qt]),
+                                                                        o[nt][qt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- store: lane holds O[query 16*qt + c][dh 16*nt + 4g .. +3]
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = qb * 64 + qt * 16 + c;
+        if (q >= Tn) continue;
+        const float inv = 1.0f / l[qt];
+        unsigned short *op = att + ((int64_t)img * Tn + q) * D + h * 64 + g * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float v[4] = {o[nt][qt][0] * inv, o[nt][qt][1] * inv, o[nt][qt][2] * inv, o[nt][qt][3] * inv};
+            El<unsigned short>::store4(op + nt * 16, v);
+        }
+    }
+}
+
 template <typename T, int EPI, int ACT>
 int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
@@ -473,22 +631,24 @@ int ivr_launch_layernorm(bool out_f32, const float *x, int row_mul, const int *o
 
 int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int D, int heads, int causal, hipStream_t s) {
     if (n <= 0) return IVR_OK;
-    const int threads = (int)ivr_round_up(T, 64);
-    IVR_REQUIRE(threads <= 512, "attention: T=%d too long for the short-sequence kernel", T);
-    const size_t lds = (size_t)2 * T * 64 * (f32 ? 4 : 2);
-    IVR_REQUIRE(lds <= 160 * 1024, "attention: T=%d needs %zu bytes of LDS", T, lds);
     // FLOP: QK^T and PV, 2*T*T*64 each per (image, head)
     IvrProf prof("attention", s, 4.0 * n * heads * (double)T * T * 64);
-    if (f32) {
-        IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        hipLaunchKernelGGL(attention_kernel<float>, dim3(heads, n), dim3(threads), lds, s, (const float *)qkv, (float *)att, T, D, causal);
-    } else {
-        IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<unsigned short>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(attention_kernel<unsigned short>, dim3(heads, n), dim3(threads), lds, s, (const unsigned short *)qkv,
-                           (unsigned short *)att, T, D, causal);
+    if (!f32) {
+        const int nqb = (T + 63) / 64;
+        const int64_t items = (int64_t)n * heads * nqb;
+        hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * VT_BYTES, s,
+                           (const unsigned short *)qkv, (unsigned short *)att, n, T, D, heads, causal);
+        IVR_LAUNCH_CHECK();
+        return IVR_OK;
     }
+    // float32 verification mode: one query per lane, K/V in LDS, VALU dot products
+    const int threads = (int)ivr_round_up(T, 64);
+    IVR_REQUIRE(threads <= 512, "attention: T=%d too long for the float32 kernel", T);
+    const size_t lds = (size_t)2 * T * 64 * 4;
+    IVR_REQUIRE(lds <= 160 * 1024, "attention: T=%d needs %zu bytes of LDS", T, lds);
+    IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    hipLaunchKernelGGL(attention_kernel<float>, dim3(heads, n), dim3(threads), lds, s, (const float *)qkv, (float *)att, T, D, causal);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
