@@ -84,6 +84,13 @@ __device__ __forceinline__ unsigned short ivr_f32_to_bf16(float f) {
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+// two floats -> packed bf16 pair with the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN)
+__device__ __forceinline__ uint32_t ivr_pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 __device__ __forceinline__ float ivr_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -257,10 +257,10 @@ template <>
 struct Out8<unsigned short> {
     static __device__ __forceinline__ void store(unsigned short *p, const float (&v)[8]) {
         uint4 o;
-        o.x = ivr_f32_to_bf16(v[0]) | ((uint32_t)ivr_f32_to_bf16(v[1]) << 16);
-        o.y = ivr_f32_to_bf16(v[2]) | ((uint32_t)ivr_f32_to_bf16(v[3]) << 16);
-        o.z = ivr_f32_to_bf16(v[4]) | ((uint32_t)ivr_f32_to_bf16(v[5]) << 16);
-        o.w = ivr_f32_to_bf16(v[6]) | ((uint32_t)ivr_f32_to_bf16(v[7]) << 16);
+        o.x = ivr_pack_bf16x2(v[0], v[1]);
+        o.y = ivr_pack_bf16x2(v[2], v[3]);
+        o.z = ivr_pack_bf16x2(v[4], v[5]);
+        o.w = ivr_pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4 *>(p) = o;
     }
     static __device__ __forceinline__ void store1(unsigned short *p, float v) { *p = ivr_f32_to_bf16(v); }

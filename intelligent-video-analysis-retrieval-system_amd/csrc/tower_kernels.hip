@@ -20,6 +20,9 @@
 #include "tower.h"
 #include "tower_kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -42,8 +45,8 @@ struct El<unsigned short> {
     }
     static __device__ __forceinline__ void store4(unsigned short *p, const float (&v)[4]) {
         uint2 o;
-        o.x = ivr_f32_to_bf16(v[0]) | ((uint32_t)ivr_f32_to_bf16(v[1]) << 16);
-        o.y = ivr_f32_to_bf16(v[2]) | ((uint32_t)ivr_f32_to_bf16(v[3]) << 16);
+        o.x = ivr_pack_bf16x2(v[0], v[1]);
+        o.y = ivr_pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<uint2 *>(p) = o;
     }
 };
@@ -55,8 +58,13 @@ struct El<float> {
     }
 };
 
+// FAST = bf16 output: v_exp + v_rcp (1 ulp each) instead of an IEEE division; the f32 verification mode keeps it exact
+template <bool FAST>
 __device__ __forceinline__ float act_fn(float x, int act) {
-    if (act == IVR_ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));   // x * sigmoid(1.702 x)
+    if (act == IVR_ACT_QUICK_GELU) {                                          // x * sigmoid(1.702 x)
+        const float e = __expf(-1.702f * x);
+        return FAST ? x * __builtin_amdgcn_rcpf(1.0f + e) : x / (1.0f + e);
+    }
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
 }
 
@@ -162,19 +170,20 @@ __global__ __launch_bounds__(256) void f_normalize_kernel(const float *__restric
 // ---------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BN = 128, ROWB = 128;            // ROWB: bytes of K per LDS row and K step
 constexpr int TILE_BYTES = BM * ROWB;                     // 16 KiB per operand per stage
 constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;              // 64 KiB
 
 template <typename T>
-__device__ __forceinline__ void mma_chunk(const uint4 &w, const uint4 &x, f32x4 &acc);
+__device__ __forceinline__ void mma_chunk(const u32x4 &w, const u32x4 &x, f32x4 &acc);
 template <>
-__device__ __forceinline__ void mma_chunk<unsigned short>(const uint4 &w, const uint4 &x, f32x4 &acc) {
+__device__ __forceinline__ void mma_chunk<unsigned short>(const u32x4 &w, const u32x4 &x, f32x4 &acc) {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), acc, 0, 0, 0);
 }
 template <>
-__device__ __forceinline__ void mma_chunk<float>(const uint4 &w, const uint4 &x, f32x4 &acc) {
+__device__ __forceinline__ void mma_chunk<float>(const u32x4 &w, const u32x4 &x, f32x4 &acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
@@ -239,21 +248,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);          // in flight under this tile's MFMAs
-        const unsigned char *cur = smem + (kt & 1) * 2 * TILE_BYTES;
-        const unsigned char *xs = cur + (wm * 64) * ROWB, *ws = cur + TILE_BYTES + (wn * 64) * ROWB;
+        // Fragment reads are inline asm on purpose: hipcc cannot prove that a ds_read of the current buffer does not
+        // alias the LDS-DMA just issued into the other one and would put s_waitcnt vmcnt(0) in front of the first
+        // compiler-visible LDS read, serialising DMA and MFMA.  lgkmcnt is counted by hand; the sched_barrier keeps the
+        // MFMAs below the wait (they only have register operands, a "memory" clobber does not order them).
+        const unsigned lbase = (unsigned)(size_t)(smem) + (kt & 1) * 2 * TILE_BYTES;
+        const unsigned xa = lbase + (wm * 64) * ROWB, wa = lbase + TILE_BYTES + (wn * 64) * ROWB;
+        u32x4 xf[2][4], wf[2][4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint4 xf[4], wf[4];
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                xf[t] = *reinterpret_cast<const uint4 *>(xs + t * 16 * ROWB + foff[kk]);
-                wf[t] = *reinterpret_cast<const uint4 *>(ws + t * 16 * ROWB + foff[kk]);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(xf[kk][t]) : "v"(xa + t * 16 * ROWB + foff[kk]));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(wf[kk][t]) : "v"(wa + t * 16 * ROWB + foff[kk]));
             }
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(wf[nt], xf[mt], acc[nt][mt]);
-        }
+            for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(wf[0][nt], xf[0][mt], acc[nt][mt]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(wf[1][nt], xf[1][mt], acc[nt][mt]);
     }
 
     // epilogue: lane holds C[m][n..n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4).
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                               acc[nt][mt][3] + bv[nt].w};
                 if (ACT >= 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = act_fn(v[i], ACT);
+                    for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
                 }
                 if (mok[mt] && nok[nt]) {
                     if (EPI == EPI_STORE)
@@ -319,6 +339,232 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                             make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM, ring version (production): 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), persistent workgroups (one per CU)
+// that walk a list of tiles, and ONE continuous LDS-DMA ring of 3 stages (48 KiB each: X 256 rows + W 128 rows of
+// 128 B) running two K steps ahead of the MFMAs - across tile boundaries too, so a tile's first stages land under
+// the previous tile's last K steps and epilogue.  Per K step: one counted wait (vmcnt(6) = the next stage's six
+// pieces of this wave may stay in flight; epilogue stores issued in between only make the wait stricter) + one
+// raw s_barrier, then the DMA for stage s+2 goes into the slot every wave finished reading before that barrier.
+// Tiles are dealt so that the 32 workgroups that share an XCD (blockIdx % 8) work on the same X row panels:
+// a panel is fetched into that XCD's L2 once and reused by all its column tiles.
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int STAGES>
+struct RingCfg {
+    static constexpr int BM_ = 64 * WM, BN_ = 64 * WN, THREADS = 64 * WM * WN;
+    static constexpr int X_BYTES = BM_ * ROWB, W_BYTES = BN_ * ROWB, STAGE_BYTES = X_BYTES + W_BYTES;
+    static constexpr int LDS = STAGES * STAGE_BYTES;
+    static constexpr int XP = 8 / WN, WP = 8 / WM;          // 1 KiB pieces per wave per stage (X, W)
+    static constexpr int INFLIGHT = (XP + WP) * (STAGES - 2);   // pieces allowed outstanding at the top of a K step
+};
+
+struct TileWalk {      // the i-th tile of this workgroup
+    int MT, NT, mode, x, j, J, G, b;
+    __device__ void init(int M, int N, int bm, int bn) {
+        MT = (M + bm - 1) / bm;
+        NT = (N + bn - 1) / bn;
+        b = blockIdx.x;
+        G = gridDim.x;
+        mode = (G % 8 == 0 && MT >= 16) ? 1 : 0;
+        x = b & 7;
+        j = b >> 3;
+        J = G >> 3;
+    }
+    __device__ int count() const {
+        if (mode == 0) {
+            const int n = MT * NT;
+            return n > b ? (n - b + G - 1) / G : 0;
+        }
+        const int panels = MT > x ? (MT - x + 7) / 8 : 0;
+        const int n = panels * NT;
+        return n > j ? (n - j + J - 1) / J : 0;
+    }
+    __device__ void get(int i, int &tm, int &tn) const {
+        if (mode == 0) {
+            const int t = b + i * G;
+            tm = t / NT;
+            tn = t % NT;
+        } else {
+            const int idx = j + i * J;
+            tm = x + 8 * (idx / NT);
+            tn = idx % NT;
+        }
+    }
+};
+
+template <typename T, int EPI, int ACT, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
+    using Cfg = RingCfg<WM, WN, STAGES>;
+    constexpr int RBM = Cfg::BM_, RBN = Cfg::BN_, RSTAGES = STAGES, RX_BYTES = Cfg::X_BYTES, RSTAGE_BYTES = Cfg::STAGE_BYTES;
+    constexpr int XP = Cfg::XP, WP = Cfg::WP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    constexpr int EPR = ROWB / (int)sizeof(T);
+    const int KT = g.K / EPR;
+    TileWalk tw;
+    tw.init(g.M, g.N, RBM, RBN);
+    const int ntiles = tw.count();
+    const int S = ntiles * KT;                       // stages this workgroup streams
+    if (S == 0) return;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // ---- producer side: wave w issues X pieces XP*w .. and W pieces WP*w .. of every stage (1 KiB each)
+    const int prow = lane >> 3, pchunk = ((lane & 7) ^ (lane >> 3)) * 16;
+    const unsigned char *srcX[XP], *srcW[WP];
+    int p_tile = -1, p_kt = 0, p_slot = 0, p_item = 0;
+    auto issue = [&]() {
+        if (p_kt == 0) {                             // first stage of a tile: per-lane source rows of this tile
+            int tm, tn;
+            tw.get(p_item, tm, tn);
+#pragma unroll
+            for (int q = 0; q < XP; ++q) {
+                const int r = min(tm * RBM + 8 * (wave * XP + q) + prow, g.M - 1);
+                srcX[q] = reinterpret_cast<const unsigned char *>(g.A) + ((int64_t)r * g.lda) * sizeof(T) + pchunk;
+            }
+#pragma unroll
+            for (int q = 0; q < WP; ++q) {
+                const int r = min(tn * RBN + 8 * (wave * WP + q) + prow, g.N - 1);
+                srcW[q] = reinterpret_cast<const unsigned char *>(g.W) + ((int64_t)r * g.ldw) * sizeof(T) + pchunk;
+            }
+        }
+        unsigned char *base = smem + p_slot * RSTAGE_BYTES;
+        const int64_t adv = (int64_t)p_kt * ROWB;
+#pragma unroll
+        for (int q = 0; q < XP; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcX[q] + adv),
+                                             (__attribute__((address_space(3))) void *)(base + (wave * XP + q) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < WP; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcW[q] + adv),
+                                             (__attribute__((address_space(3))) void *)(base + RX_BYTES + (wave * WP + q) * 1024), 16, 0,
+                                             0);
+        if (++p_kt == KT) {
+            p_kt = 0;
+            ++p_item;
+        }
+        p_slot = p_slot == RSTAGES - 1 ? 0 : p_slot + 1;
+    };
+    (void)p_tile;
+
+    // ---- consumer side
+    int foff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) foff[kk] = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+    f32x4 acc[4][4];   // [nt][mt]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int q = 0; q < STAGES - 1 && q < S; ++q) issue();
+    int c_kt = 0, c_slot = 0, c_item = 0;
+    for (int s = 0; s < S; ++s) {
+        // stage s has landed for this wave once at most the pieces of the STAGES-2 younger stages are outstanding; the
+        // barrier then makes that true for every wave and also orders every wave's reads of the slot refilled below
+        if (s + STAGES - 1 <= S)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Cfg::INFLIGHT) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + STAGES - 1 < S) issue();
+        const unsigned lbase = lds0 + c_slot * RSTAGE_BYTES;
+        const unsigned xa = lbase + (wm * 64) * ROWB, wa = lbase + RX_BYTES + (wn * 64) * ROWB;
+        u32x4 xf[2][4], wf[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(xf[kk][t]) : "v"(xa + t * 16 * ROWB + foff[kk]));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(wf[kk][t]) : "v"(wa + t * 16 * ROWB + foff[kk]));
+            }
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(wf[0][nt], xf[0][mt], acc[nt][mt]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(wf[1][nt], xf[1][mt], acc[nt][mt]);
+        c_slot = c_slot == RSTAGES - 1 ? 0 : c_slot + 1;
+        if (++c_kt < KT) continue;
+
+        // ---- tile finished: epilogue (same register layout as gemm_kernel), then reset the accumulators
+        c_kt = 0;
+        int tm, tn;
+        tw.get(c_item++, tm, tn);
+        const int m0 = tm * RBM, n0 = tn * RBN;
+        int mrow[4], ncol[4];
+        bool mok[4], nok[4];
+        float4 bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            mrow[t] = m0 + wm * 64 + t * 16 + (lane & 15);
+            ncol[t] = n0 + wn * 64 + t * 16 + 4 * (lane >> 4);
+            mok[t] = mrow[t] < g.M;
+            nok[t] = ncol[t] < g.N;
+            mrow[t] = min(mrow[t], g.M - 1);
+            ncol[t] = min(ncol[t], g.N - 4);
+            bv[t] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + ncol[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (EPI == EPI_RESID || EPI == EPI_PATCH) {
+            float4 rv[4][4];
+            float *rowp[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (EPI == EPI_RESID) {
+                    rowp[mt] = g.resid + (int64_t)mrow[mt] * g.ldr;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) rv[mt][nt] = *reinterpret_cast<const float4 *>(rowp[mt] + ncol[nt]);
+                } else {
+                    const int img = mrow[mt] / g.G2, pch = mrow[mt] % g.G2;
+                    rowp[mt] = g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        rv[mt][nt] = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol[nt]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float4 r = rv[mt][nt];
+                    r.x += acc[nt][mt][0] + bv[nt].x;
+                    r.y += acc[nt][mt][1] + bv[nt].y;
+                    r.z += acc[nt][mt][2] + bv[nt].z;
+                    r.w += acc[nt][mt][3] + bv[nt].w;
+                    if (mok[mt] && nok[nt]) *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float v[4] = {acc[nt][mt][0] + bv[nt].x, acc[nt][mt][1] + bv[nt].y, acc[nt][mt][2] + bv[nt].z,
+                                  acc[nt][mt][3] + bv[nt].w};
+                    if (ACT >= 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
+                    }
+                    if (mok[mt] && nok[nt]) {
+                        if (EPI == EPI_STORE)
+                            El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt], v);
+                        else
+                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt]) =
+                                make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -539,10 +785,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 f;
-                f.x = ivr_f32_to_bf16(s[2 * ks][qt][0]) | ((uint32_t)ivr_f32_to_bf16(s[2 * ks][qt][1]) << 16);
-                f.y = ivr_f32_to_bf16(s[2 * ks][qt][2]) | ((uint32_t)ivr_f32_to_bf16(s[2 * ks][qt][3]) << 16);
-                f.z = ivr_f32_to_bf16(s[2 * ks + 1][qt][0]) | ((uint32_t)ivr_f32_to_bf16(s[2 * ks + 1][qt][1]) << 16);
-                f.w = ivr_f32_to_bf16(s[2 * ks + 1][qt][2]) | ((uint32_t)ivr_f32_to_bf16(s[2 * ks + 1][qt][3]) << 16);
+                f.x = ivr_pack_bf16x2(s[2 * ks][qt][0], s[2 * ks][qt][1]);
+                f.y = ivr_pack_bf16x2(s[2 * ks][qt][2], s[2 * ks][qt][3]);
+                f.z = ivr_pack_bf16x2(s[2 * ks + 1][qt][0], s[2 * ks + 1][qt][1]);
+                f.w = ivr_pack_bf16x2(s[2 * ks + 1][qt][2], s[2 * ks + 1][qt][3]);
                 pf[ks][qt] = f;
             }
         }
@@ -576,8 +822,51 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
     }
 }
 
+// kernel choice, overridable for A/B runs: IVR_GEMM=0 one-tile-per-workgroup 128x128 kernel, 1 persistent 128x128
+// (2 stages, 2 workgroups per CU), 2 persistent 256x128 (3 stages, 1 workgroup per CU)
+int ring_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("IVR_GEMM");
+        v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+    }
+    return v;
+}
+
 template <typename T, int EPI, int ACT>
 int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
+    IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
+    const int mode = ring_mode();
+    if (mode == 1 || mode == 2) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (mode == 1) {            // 128 x 128, 4 waves, 2 stages, two persistent workgroups per CU
+            using Cfg = RingCfg<2, 2, 2>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_kernel<T, EPI, ACT, 2, 2, 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
+                attr_done = true;
+            }
+            const int MT = (g.M + Cfg::BM_ - 1) / Cfg::BM_, NT = (g.N + Cfg::BN_ - 1) / Cfg::BN_;
+            const int grid = std::min(MT * NT, 2 * cus);
+            hipLaunchKernelGGL((gemm_ring_kernel<T, EPI, ACT, 2, 2, 2>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS, s, g);
+        } else {                    // 256 x 128, 8 waves, 3 stages, one persistent workgroup per CU
+            using Cfg = RingCfg<4, 2, 3>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_kernel<T, EPI, ACT, 4, 2, 3>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
+                attr_done = true;
+            }
+            const int MT = (g.M + Cfg::BM_ - 1) / Cfg::BM_, NT = (g.N + Cfg::BN_ - 1) / Cfg::BN_;
+            const int grid = std::min(MT * NT, cus);
+            hipLaunchKernelGGL((gemm_ring_kernel<T, EPI, ACT, 4, 2, 3>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS, s, g);
+        }
+        IVR_LAUNCH_CHECK();
+        return IVR_OK;
+    }
     const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
     static bool attr_done = false;
     if (!attr_done) {
@@ -585,7 +874,6 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
         attr_done = true;
     }
-    IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
     hipLaunchKernelGGL((gemm_kernel<T, EPI, ACT>), dim3(MT * NT), dim3(256), GEMM_LDS, s, g);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
