@@ -27,6 +27,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PMC_NAME = {"scan_groupmax": "scan_groupmax_kernel<1>", "preprocess_emit": "emit_vec_kernel<bf16>"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
 
@@ -89,10 +90,17 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    local_rank = local_rank % max(1, torch.cuda.device_count())   # rehearsal: more ranks than GPUs share devices
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" is RCCL on ROCm (xGMI between the GPUs of the node); IVR_DIST_BACKEND=gloo only for rehearsing the
+        # multi-rank control flow on a box with fewer GPUs than ranks
+        backend = os.environ.get("IVR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ivr_amd import _ffi
     from ivr_amd import config as C
@@ -167,6 +175,21 @@ def main():
 
     if rank == 0:
         frames_total = B * args.steps * world
+        # HBM bytes per launch from the committed PMC passes of this same command (tools/pmc_aggregate.py); null when the
+        # profile was taken at another batch size
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+        except OSError:
+            pass
+        pmc_ok = B == 2048 and N == 1_000_000
+
+        def traffic(*kernels):
+            if not pmc_ok or not all(k in pmc for k in kernels):
+                return None
+            tot = sum(pmc[k]["hbm_bytes"] * pmc[k]["launches"] for k in kernels)
+            return tot / sum(pmc[k]["launches"] for k in kernels)
         gemm = {n: v for n, v in prof.items() if n.startswith("gemm_")}
         gemm_flop = sum(v["work"] for v in gemm.values())
         gemm_ms = sum(v["ms"] for v in gemm.values())
@@ -178,8 +201,8 @@ def main():
             if not v or not v["ms"]:
                 return None
             a = v["work"] / (v["ms"] * 1e-3) / 1e9
-            return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": name, "avg_launch_ms": v["ms"] / v["launches"], "launches": int(v["launches"]),
+            return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                    "traffic": traffic(PMC_NAME[name]), "kernel": name, "avg_launch_ms": v["ms"] / v["launches"], "launches": int(v["launches"]),
                     "bytes_per_launch": v["work"] / v["launches"]}
 
         out = {
@@ -193,7 +216,9 @@ def main():
                        "parallelism": f"{world} x (frames + index rows sharded per GPU); one all-gather of (score,id) + merge"},
             "pairs_per_s": N * world * Q / (search_ms * 1e-3), "search_ms_per_step": search_ms,
             "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TF,
-                         "traffic": None, "kernel": "gemm_kernel<bf16> (all tower GEMM launches of the timed region)",
+                         "traffic": traffic("gemm_kernel<bf16, 0, -1>", "gemm_kernel<bf16, 0, 0>", "gemm_kernel<bf16, 1, -1>",
+                                            "gemm_kernel<bf16, 2, -1>", "gemm_kernel<bf16, 3, -1>"),
+                         "kernel": "gemm_kernel<bf16> (all tower GEMM launches of the timed region)",
                          "avg_launch_ms": gemm_ms / max(1, gemm_launches), "launches": int(gemm_launches),
                          "flop_per_launch": gemm_flop / max(1, gemm_launches),
                          "by_call_site": {n: {"TFLOP/s": v["work"] / (v["ms"] * 1e-3) / 1e12, "ms": v["ms"] / v["launches"]}
