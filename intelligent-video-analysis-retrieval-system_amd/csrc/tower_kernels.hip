@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void f_normalize_kernel(const float *__restric
 // GEMM
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int BM = 128, BN = 128, ROWB = 128;            // ROWB: bytes of K per LDS row and K step
 constexpr int TILE_BYTES = BM * ROWB;                     // 16 KiB per operand per stage
 constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;              // 64 KiB
@@ -193,7 +194,8 @@ __device__ __forceinline__ void mma_chunk<float>(const u32x4 &w, const u32x4 &x,
 template <typename T, int EPI, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: keeps the DMA addressing scalar
     const int wm = wave >> 1, wn = wave & 1;
     const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
     // bijective XCD remap: workgroups b, b+8, b+16, ... share an XCD; give each XCD a contiguous id range
@@ -207,34 +209,42 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     const int m0 = tm * BM, n0 = tn * BN;
     constexpr int EPR = ROWB / (int)sizeof(T);   // elements of K per step
     const int KT = g.K / EPR;
+    const unsigned lds0 = (unsigned)(size_t)smem;
 
-    // staging: LDS-DMA (global_load_lds_dwordx4).  One wave instruction fills 8 rows x 128 B = 1 KiB: lane l lands
-    // at (wave-uniform base) + 16*l, i.e. row 8i + (l >> 3), chunk position l & 7.  The XOR swizzle therefore goes
-    // on the SOURCE: the lane fetches logical chunk (l & 7) ^ (row & 7) of its row, and fragment reads apply the
-    // same involution.  16 such pieces per operand per K step; wave w issues pieces 4w .. 4w+3 of X and of W.
-    const unsigned char *srcX[4], *srcW[4];
+    // staging: LDS-DMA (buffer_load_dwordx4 ... lds).  One wave instruction fills 8 rows x 128 B = 1 KiB: lane l lands at
+    // (wave-uniform M0 base) + 16*l, i.e. row 8i + (l >> 3), chunk position l & 7.  The XOR swizzle therefore goes on the
+    // SOURCE: the lane fetches logical chunk (l & 7) ^ (row & 7) of its row, and fragment reads apply the same involution.
+    // 16 such pieces per operand per K step; wave w issues pieces 4w .. 4w+3 of X and of W.  The per-lane address part is
+    // a constant voffset; tile origin and K step are a scalar soffset; rows past the matrix end read as zeros.
+    unsigned voffX[4], voffW[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 8 * (wave * 4 + j) + (lane >> 3), c = (lane & 7) ^ (lane >> 3);
-        const int xm = min(m0 + r, g.M - 1), wr = min(n0 + r, g.N - 1);
-        srcX[j] = reinterpret_cast<const unsigned char *>(g.A) + ((int64_t)xm * g.lda) * sizeof(T) + c * 16;
-        srcW[j] = reinterpret_cast<const unsigned char *>(g.W) + ((int64_t)wr * g.ldw) * sizeof(T) + c * 16;
+        voffX[j] = (unsigned)(r * g.lda) * (unsigned)sizeof(T) + c * 16;
+        voffW[j] = (unsigned)(r * g.ldw) * (unsigned)sizeof(T) + c * 16;
     }
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.A), 0, (int)((int64_t)g.M * g.lda * sizeof(T)), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * sizeof(T)), 0x00020000);
+    const unsigned sx0 = (unsigned)m0 * (unsigned)g.lda * (unsigned)sizeof(T), sw0 = (unsigned)n0 * (unsigned)g.ldw * (unsigned)sizeof(T);
     auto stage = [&](int kt, int buf) {
         unsigned char *base = smem + buf * 2 * TILE_BYTES + (wave * 4) * 1024;
-        const int64_t adv = (int64_t)kt * ROWB;
+        const unsigned adv = (unsigned)kt * ROWB;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcX[j] + adv),
-                                             (__attribute__((address_space(3))) void *)(base + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcW[j] + adv),
-                                             (__attribute__((address_space(3))) void *)(base + TILE_BYTES + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + j * 1024), 16, voffX[j],
+                                                     sx0 + adv, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + TILE_BYTES + j * 1024), 16,
+                                                     voffW[j], sw0 + adv, 0, 0);
         }
     };
-    // fragment read offsets inside a 16-row tile for the two 64-byte halves of a row
-    int foff[2];
+    // per-lane fragment offsets (operand, kk) inside a buffer; the four 16-row tiles are immediate offsets
+    unsigned foX[2], foW[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) foff[kk] = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+    for (int kk = 0; kk < 2; ++kk) {
+        const unsigned f = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+        foX[kk] = lds0 + (wm * 64) * ROWB + f;
+        foW[kk] = lds0 + TILE_BYTES + (wn * 64) * ROWB + f;
+    }
 
     f32x4 acc[4][4];   // [nt][mt]
 #pragma unroll
@@ -245,23 +255,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     stage(0, 0);
     for (int kt = 0; kt < KT; ++kt) {
         // tile kt has landed for every wave, and every wave is done reading the other buffer (tile kt-1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);          // in flight under this tile's MFMAs
         // Fragment reads are inline asm on purpose: hipcc cannot prove that a ds_read of the current buffer does not
         // alias the LDS-DMA just issued into the other one and would put s_waitcnt vmcnt(0) in front of the first
         // compiler-visible LDS read, serialising DMA and MFMA.  lgkmcnt is counted by hand; the sched_barrier keeps the
         // MFMAs below the wait (they only have register operands, a "memory" clobber does not order them).
-        const unsigned lbase = (unsigned)(size_t)(smem) + (kt & 1) * 2 * TILE_BYTES;
-        const unsigned xa = lbase + (wm * 64) * ROWB, wa = lbase + TILE_BYTES + (wn * 64) * ROWB;
+        const unsigned boff = (kt & 1) * 2 * TILE_BYTES;
         u32x4 xf[2][4], wf[2][4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                asm volatile("ds_read_b128 %0, %1" : "=v"(xf[kk][t]) : "v"(xa + t * 16 * ROWB + foff[kk]));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(wf[kk][t]) : "v"(wa + t * 16 * ROWB + foff[kk]));
-            }
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned xa = foX[kk] + boff, wa = foW[kk] + boff;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xf[kk][0]) : "v"(xa));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(wf[kk][0]) : "v"(wa));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(xf[kk][1]) : "v"(xa));
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[kk][1]) : "v"(wa));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(xf[kk][2]) : "v"(xa));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(wf[kk][2]) : "v"(wa));
+            asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(xf[kk][3]) : "v"(xa));
+            asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(wf[kk][3]) : "v"(wa));
+        }
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -569,6 +582,239 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// GEMM, stream version: one persistent 4-wave workgroup per CU (one wave per SIMD), 128 x 128 tile, and a
+// 4-slot LDS-DMA ring kept THREE K steps (96 KiB) ahead of the MFMAs, continuously across tile boundaries.
+// Nothing the compiler can see ever loads from global memory, so it inserts no s_waitcnt vmcnt of its own:
+//   * operand tiles: global_load_lds (8 x 1 KiB pieces per wave per stage);
+//   * bias / residual / position rows: inline-asm global_load_dwordx4 issued at the START of a tile and consumed in its
+//     epilogue (>= 4 counted waits later, so they have retired);
+//   * outputs: raw buffer stores - always issued, out-of-range lanes are clipped by the descriptor - so the number
+//     of vector-memory operations per tile is exact and every wait can be COUNTED:
+//       at the top of K step s the wave may leave outstanding everything younger than stage s's DMA, i.e. the two
+//       younger stages (16 pieces) + the previous tile's 16 stores + this tile's NL tile-start loads, depending on the
+//       position c of the step in its tile:   c <= 2: 32 + NL (first tile: 16 + NL)      c >= 3: 16.
+// ---------------------------------------------------------------------------------------------
+constexpr int SSTAGES = 4, STILE = 2 * TILE_BYTES, STREAM_LDS = SSTAGES * STILE;   // 128 KiB
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <typename T, int EPI, int ACT, bool HASBIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_stream_kernel(GemmArgs g) {
+    constexpr int NL = (HASBIAS ? 4 : 0) + ((EPI == EPI_RESID || EPI == EPI_PATCH) ? 16 : 0);
+    static_assert(32 + NL <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: keeps the DMA addressing scalar
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int EPR = ROWB / (int)sizeof(T);
+    const int KT = g.K / EPR;                        // host guarantees KT >= 4
+    TileWalk tw;
+    tw.init(g.M, g.N, BM, BN);
+    const int ntiles = tw.count();
+    const int S = ntiles * KT;
+    if (S == 0) return;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // ---- producer: wave w moves X rows 32w..32w+31 and W rows 32w..32w+31 of every stage (4 + 4 pieces of 1 KiB) with
+    // buffer_load ... lds: the per-lane part of the address (row inside the tile, swizzled 16-byte chunk) is a constant
+    // voffset, everything that changes (tile origin, K step, ring slot) is SCALAR (soffset, M0): no vector ALU work per
+    // stage.  Rows past the end of a matrix read as zeros through the descriptor's bounds check.
+    const int prow = lane >> 3, pchunk = ((lane & 7) ^ (lane >> 3)) * 16;
+    unsigned voffX[4], voffW[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 8 * (wave * 4 + q) + prow;
+        voffX[q] = (unsigned)(r * g.lda) * (unsigned)sizeof(T) + pchunk;
+        voffW[q] = (unsigned)(r * g.ldw) * (unsigned)sizeof(T) + pchunk;
+    }
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.A), 0, (int)((int64_t)g.M * g.lda * sizeof(T)), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * sizeof(T)), 0x00020000);
+    int p_kt = 0, p_slot = 0, p_item = 0;
+    unsigned p_sx = 0, p_sw = 0;                      // scalar byte offsets of the tile being streamed
+    auto issue = [&]() {
+        if (p_kt == 0) {
+            int tm, tn;
+            tw.get(p_item, tm, tn);
+            p_sx = (unsigned)(tm * BM) * (unsigned)g.lda * (unsigned)sizeof(T);
+            p_sw = (unsigned)(tn * BN) * (unsigned)g.ldw * (unsigned)sizeof(T);
+        }
+        unsigned char *base = smem + p_slot * STILE + (wave * 4) * 1024;
+        const unsigned adv = (unsigned)p_kt * ROWB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + q * 1024), 16, voffX[q],
+                                                     p_sx + adv, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + TILE_BYTES + q * 1024), 16,
+                                                     voffW[q], p_sw + adv, 0, 0);
+        }
+        if (++p_kt == KT) {
+            p_kt = 0;
+            ++p_item;
+        }
+        p_slot = (p_slot + 1) & (SSTAGES - 1);
+    };
+
+    // ---- consumer state: per-lane fragment offsets (operand, kk) inside a ring slot; tile rows as immediates
+    unsigned foX[2], foW[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const unsigned f = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+        foX[kk] = lds0 + (wm * 64) * ROWB + f;
+        foW[kk] = lds0 + TILE_BYTES + (wn * 64) * ROWB + f;
+    }
+    // output descriptors: out-of-range rows/columns are clipped by num_records, never by exec
+    const unsigned out_elem = EPI == EPI_STORE ? (unsigned)sizeof(T) : 4u;
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        (EPI == EPI_RESID || EPI == EPI_PATCH) ? (void *)g.resid : g.out, 0,
+        (EPI == EPI_PATCH) ? (int)0x7fffffff
+                           : (int)min((int64_t)0x7fffffff, (int64_t)g.M * ((EPI == EPI_RESID) ? g.ldr : g.ldo) * out_elem),
+        0x00020000);
+    // tile-start loads land in the ACCUMULATOR half of the register file ("a" constraint): 80 registers that would
+    // otherwise push the MFMA accumulators out of the architectural VGPRs and back every K step
+    u32x4 bvr[4];          // bias quads of this lane's 4 column groups
+    u32x4 rvr[4][4];       // residual / position quads [mt][nt]
+    int mrow[4], ncol[4];
+    bool nok[4];
+
+    // Software pipeline (one wave per SIMD has nobody else to hide its LDS latency): the kk = 0 fragments of stage s+1 are
+    // read while the kk = 1 MFMAs of stage s run, so every ds_read burst sits under 16 MFMAs.  That needs stage s+1
+    // landed one half-step early: the counted wait + barrier sits in the MIDDLE of step s and waits for stage s+1,
+    // leaving stage s+2 (8 pieces) in flight; DMA for stage s+3 is issued right after it into the slot of stage s-1.
+    // Younger than stage s+1's DMA at that wait: stage s+2, and for the first two K steps of a tile also the previous
+    // tile's 16 stores and this tile's NL tile-start loads.  Two K steps per trip so the fragment sets ping-pong
+    // between two register groups with no copy of an in-flight register.
+#define IVR_READ_FRAGS(DSTX, DSTW, SLOT, KK)                                                                            \
+    {                                                                                                                   \
+        const unsigned xa_ = foX[KK] + (SLOT) * STILE, wa_ = foW[KK] + (SLOT) * STILE;                                  \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(DSTX[0]) : "v"(xa_));                                                 \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(DSTW[0]) : "v"(wa_));                                                 \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(DSTX[1]) : "v"(xa_));                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(DSTW[1]) : "v"(wa_));                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(DSTX[2]) : "v"(xa_));                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(DSTW[2]) : "v"(wa_));                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(DSTX[3]) : "v"(xa_));                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(DSTW[3]) : "v"(wa_));                                     \
+    }
+#define IVR_MMA16(FX, FW)                                                                                               \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                   \
+        mma_chunk<T>(FW[nt], FX[mt], acc[nt][mt]);
+#define IVR_LGKM(N)                                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int q = 0; q < SSTAGES - 1 && q < S; ++q) issue();
+    int c_slot = 0, s = 0;
+    u32x4 ax[4], aw[4], bx[4], bw[4], gx[4], gw[4];     // A / B: kk = 0 sets (ping-pong), G: kk = 1 set
+    for (int item = 0; item < ntiles; ++item) {
+        // ---- tile-start loads (inline asm: invisible to the compiler's waitcnt pass, always issued, NL per wave)
+        {
+            int tm, tn;
+            tw.get(item, tm, tn);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                mrow[t] = tm * BM + wm * 64 + t * 16 + (lane & 15);
+                ncol[t] = tn * BN + wn * 64 + t * 16 + 4 * (lane >> 4);
+                nok[t] = ncol[t] < g.N;
+            }
+            if (HASBIAS) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bvr[t]) : "v"(g.bias + min(ncol[t], g.N - 4)));
+            }
+            if (EPI == EPI_RESID || EPI == EPI_PATCH) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int mr = min(mrow[mt], g.M - 1);
+                    const float *rowp = EPI == EPI_RESID ? g.resid + (int64_t)mr * g.ldr : g.pos + (int64_t)(1 + mr % g.G2) * g.N;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(rvr[mt][nt]) : "v"(rowp + min(ncol[nt], g.N - 4)));
+                }
+            }
+        }
+        if (item == 0) {
+            // stage 0 must have landed before its first fragment read: younger than its DMA are stages 1, 2 and the loads
+            if (S > 2) wait_vm_barrier<16 + NL>(); else wait_vm_barrier<0>();
+            IVR_READ_FRAGS(ax, aw, 0, 0)
+        }
+        f32x4 acc[4][4];   // [nt][mt]
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < KT; kt += 2) {           // host guarantees KT even
+#pragma unroll
+            for (int half = 0; half < 2; ++half, ++s) {
+                const int c = kt + half;
+                const int nslot = (c_slot + 1) & (SSTAGES - 1);
+                // kk = 1 fragments of this stage, then the kk = 0 MFMAs (their operands were read one half-step ago)
+                IVR_READ_FRAGS(gx, gw, c_slot, 1)
+                IVR_LGKM(8)
+                if (half == 0) { IVR_MMA16(ax, aw) } else { IVR_MMA16(bx, bw) }
+                // stage s+1 for everybody (nothing to wait for after the last stage)
+                if (s + 1 < S) {
+                    if (s + 2 >= S) wait_vm_barrier<0>();
+                    else if (c >= 2) wait_vm_barrier<8>();
+                    else if (item == 0) wait_vm_barrier<8 + NL>();
+                    else wait_vm_barrier<24 + NL>();
+                    if (s + SSTAGES - 1 < S) issue();
+                    if (half == 0) { IVR_READ_FRAGS(bx, bw, nslot, 0) } else { IVR_READ_FRAGS(ax, aw, nslot, 0) }
+                    IVR_LGKM(8)
+                } else {
+                    IVR_LGKM(0)
+                }
+                IVR_MMA16(gx, gw)
+                c_slot = nslot;
+            }
+        }
+
+        // ---- epilogue.  The tile-start loads retired long ago (>= KT counted waits since); tell the compiler their
+        // registers are now defined, then exactly 16 buffer stores per wave.
+        if (HASBIAS) asm volatile("" : "+a"(bvr[0]), "+a"(bvr[1]), "+a"(bvr[2]), "+a"(bvr[3]));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (EPI == EPI_RESID || EPI == EPI_PATCH)
+                asm volatile("" : "+a"(rvr[mt][0]), "+a"(rvr[mt][1]), "+a"(rvr[mt][2]), "+a"(rvr[mt][3]));
+            // row of the destination (EPI_PATCH scatters patch rows to token rows); rows >= M are clipped below
+            int64_t drow = mrow[mt];
+            if (EPI == EPI_PATCH) drow = (int64_t)(mrow[mt] / g.G2) * g.T + 1 + mrow[mt] % g.G2;
+            const bool mok = mrow[mt] < g.M;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+                if (HASBIAS) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += __uint_as_float(bvr[nt][i]);
+                }
+                if (EPI == EPI_RESID || EPI == EPI_PATCH) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += __uint_as_float(rvr[mt][nt][i]);
+                }
+                if (ACT >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
+                }
+                const int ld = (EPI == EPI_RESID || EPI == EPI_PATCH) ? g.ldr : g.ldo;
+                // byte offset; 0xffffffff (clipped by the descriptor) for rows / columns outside the matrix
+                const int64_t off = (drow * ld + ncol[nt]) * (int64_t)out_elem;
+                const unsigned voff = (mok && nok[nt] && off < 0x7fffffff) ? (unsigned)off : 0xffffffffu;
+                if (EPI == EPI_STORE && sizeof(T) == 2) {
+                    u32x2 d = {ivr_pack_bf16x2(v[0], v[1]), ivr_pack_bf16x2(v[2], v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(d, rs_out, voff, 0, 0);
+                } else {
+                    u32x4 d = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs_out, voff, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // attention for short sequences (T = 50 / 77 / 197 / 257, head_dim 64): one workgroup per
 // (head, image); K and V of the head staged in LDS, one query row per lane, float32 online softmax.
 // The 1/sqrt(64) scale is folded into the Q weights at upload (exact: a power of two).
@@ -823,12 +1069,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
 }
 
 // kernel choice, overridable for A/B runs: IVR_GEMM=0 one-tile-per-workgroup 128x128 kernel, 1 persistent 128x128
-// (2 stages, 2 workgroups per CU), 2 persistent 256x128 (3 stages, 1 workgroup per CU)
+// (2 stages, 2 workgroups per CU), 2 persistent 256x128 (3 stages, 1 workgroup per CU), 3 stream kernel (4-stage ring,
+// counted waits, one 4-wave workgroup per CU)
 int ring_mode() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("IVR_GEMM");
-        v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+        v = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0;
     }
     return v;
 }
@@ -837,6 +1084,36 @@ template <typename T, int EPI, int ACT>
 int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
     const int mode = ring_mode();
+    // the stream kernel needs >= 4 K steps per tile, outputs below 2 GiB (32-bit buffer offsets) and enough tiles
+    const int64_t out_bytes = (int64_t)g.M * std::max(g.ldo, g.ldr) * 4;
+    const int kt_steps = g.K / (ROWB / (int)sizeof(T));
+    const bool fits32 = (int64_t)g.M * g.lda * (int64_t)sizeof(T) < 0x7fffffff && (int64_t)g.N * g.ldw * (int64_t)sizeof(T) < 0x7fffffff;
+    if (mode == 3 && kt_steps >= 4 && kt_steps % 2 == 0 && out_bytes < 0x7fffffff && fits32 && (EPI != EPI_PATCH || g.resid)) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
+        const int grid = std::min(MT * NT, cus);
+        if (g.bias) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_stream_kernel<T, EPI, ACT, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((gemm_stream_kernel<T, EPI, ACT, true>), dim3(grid), dim3(256), STREAM_LDS, s, g);
+        } else {
+            static bool attr_done = false;
+            if (!attr_done) {
+                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_stream_kernel<T, EPI, ACT, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((gemm_stream_kernel<T, EPI, ACT, false>), dim3(grid), dim3(256), STREAM_LDS, s, g);
+        }
+        IVR_LAUNCH_CHECK();
+        return IVR_OK;
+    }
     if (mode == 1 || mode == 2) {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
@@ -899,6 +1176,10 @@ int ivr_launch_gemm(bool f32, int epi, const GemmArgs &g, hipStream_t s) {
     const int epr = f32 ? 32 : 64;
     IVR_REQUIRE(g.K > 0 && g.K % epr == 0, "gemm: K=%d must be a multiple of %d", g.K, epr);
     IVR_REQUIRE(g.N % 4 == 0, "gemm: N=%d must be a multiple of 4", g.N);
+    const int64_t es = f32 ? 4 : 2;
+    IVR_REQUIRE((int64_t)g.M * g.lda * es < 0x7fffffff && (int64_t)g.N * g.ldw * es < 0x7fffffff,
+                "gemm: an operand exceeds the 2 GiB reach of the 32-bit buffer offsets (M=%d lda=%d N=%d ldw=%d): use a smaller batch",
+                g.M, g.lda, g.N, g.ldw);
     return f32 ? launch_gemm_e<float>(epi, g, s) : launch_gemm_e<unsigned short>(epi, g, s);
 }
 
