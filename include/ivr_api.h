@@ -159,6 +159,10 @@ int ivr_index_add(ivr_index *idx, const float *rows /*DEV*/, int64_t n, int norm
 /* overwrite rows [start, start+n) (ring-buffer use, BASELINE config 4); start+n <= ntotal. */
 int ivr_index_write(ivr_index *idx, int64_t start, const float *rows /*DEV*/, int64_t n, int normalize,
                     ivr_stream stream);
+/* rolling-window variant for a captured (hipGraph) streaming step: overwrite the n rows at *cursor (DEV int64, a multiple of
+ * n; n must divide ntotal) and advance the cursor by n modulo ntotal, all on the stream. */
+int ivr_index_write_ring(ivr_index *idx, const float *rows /*DEV*/, int64_t n, int normalize, int64_t *cursor /*DEV*/,
+                         ivr_stream stream);
 /* copy rows [start, start+n) back to row-major float32 (faiss reconstruct_n). */
 int ivr_index_reconstruct(ivr_index *idx, int64_t start, int64_t n, float *out /*DEV*/, ivr_stream stream);
 /* pre-size the search workspace so that ivr_index_search allocates nothing (hipGraph capture). */

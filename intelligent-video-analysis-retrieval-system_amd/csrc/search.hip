@@ -44,7 +44,9 @@ __device__ __forceinline__ float4 load_quad(const float *__restrict__ row, int k
 // one wave per 16-row tile; lane l owns row (l & 15) and quad (l >> 4) of every 16-float chunk
 __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                         int64_t row_start, int64_t n, int d, int dp4,
-                                                        int normalize, int32_t *__restrict__ nonfinite) {
+                                                        int normalize, int32_t *__restrict__ nonfinite,
+                                                        const int64_t *__restrict__ start_dev) {
+    if (start_dev) row_start = *start_dev;          // ring cursor kept in HBM so a captured graph can replay it
     const int lane = threadIdx.x & 63;
     const int64_t tile0 = row_start >> 4;
     const int64_t ntiles = ((row_start + n + 15) >> 4) - tile0;
@@ -119,6 +121,8 @@ __global__ __launch_bounds__(256) void untile_rows_kernel(const float *__restric
         if (k0 + 3 < d) drow[k0 + 3] = v.w;
     }
 }
+
+__global__ void advance_cursor_kernel(int64_t *cursor, int64_t n, int64_t modulo) { *cursor = (*cursor + n) % modulo; }
 
 // in-place row normalisation of a row-major matrix (ivr_l2_normalize): one wave per row
 __global__ __launch_bounds__(256) void l2_normalize_kernel(float *__restrict__ x, int64_t n, int d,
@@ -457,7 +461,8 @@ int launch_tile_rows(ivr_index *x, float *dst, const float *src, int64_t start, 
     const int64_t ntiles = ((start + n + 15) >> 4) - (start >> 4);
     const unsigned grid = (unsigned)ivr_ceil_div(ntiles, 4);
     IvrProf prof("tile_rows", s, (double)n * (x->d + x->dp) * 4);
-    hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, src, dst, start, n, x->d, x->dp4, normalize, nonfinite);
+    hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, src, dst, start, n, x->d, x->dp4, normalize, nonfinite,
+                       (const int64_t *)nullptr);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
@@ -589,6 +594,27 @@ int ivr_index_write(ivr_index *x, int64_t start, const float *rows, int64_t n, i
                 (long long)start, (long long)(start + n), (long long)x->ntotal);
     IVR_HIP(hipSetDevice(x->ctx->device));
     return launch_tile_rows(x, x->data, rows, start, n, normalize, nullptr, (hipStream_t)stream);
+}
+
+int ivr_index_write_ring(ivr_index *x, const float *rows, int64_t n, int normalize, int64_t *cursor, ivr_stream stream) {
+    IVR_REQUIRE(x && rows && cursor, "ivr_index_write_ring: NULL argument");
+    std::lock_guard<std::mutex> lk(x->mu);
+    IVR_REQUIRE(n >= 1 && x->ntotal >= n && x->ntotal % n == 0,
+                "ivr_index_write_ring: batch of %lld rows must divide ntotal=%lld (no wrap inside a batch)", (long long)n,
+                (long long)x->ntotal);
+    IVR_HIP(hipSetDevice(x->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    // the cursor is only known on the device: launch for the worst-case number of touched tiles
+    const unsigned grid = (unsigned)ivr_ceil_div(ivr_ceil_div(n, 16) + 1, 4);
+    {
+        IvrProf prof("tile_rows", s, (double)n * (x->d + x->dp) * 4);
+        hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, rows, x->data, (int64_t)0, n, x->d, x->dp4, normalize,
+                           (int32_t *)nullptr, (const int64_t *)cursor);
+    }
+    IVR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(advance_cursor_kernel, dim3(1), dim3(1), 0, s, cursor, n, x->ntotal);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
 }
 
 int ivr_index_reconstruct(ivr_index *x, int64_t start, int64_t n, float *out, ivr_stream stream) {

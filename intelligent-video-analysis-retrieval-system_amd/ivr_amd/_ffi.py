@@ -55,6 +55,7 @@ _SIGS = {
     "ivr_index_capacity": (_i64, [_p]),
     "ivr_index_add": (_i, [_p, _p, _i64, _i, _p]),
     "ivr_index_write": (_i, [_p, _i64, _p, _i64, _i, _p]),
+    "ivr_index_write_ring": (_i, [_p, _p, _i64, _i, _p, _p]),
     "ivr_index_reconstruct": (_i, [_p, _i64, _i64, _p, _p]),
     "ivr_index_reserve_search": (_i, [_p, _i, _i]),
     "ivr_index_search": (_i, [_p, _p, _i, _i, _i, _i64, _p, _p, _p]),

@@ -102,6 +102,14 @@ class FlatIPIndex:
             _ffi.check(self._lib.ivr_index_write(self._h, int(start), C.c_void_p(rows.data_ptr()), rows.shape[0],
                                                  int(bool(normalize)), _ffi.stream_ptr()), "ivr_index_write")
 
+    def write_ring(self, rows, cursor, normalize=False):
+        """Overwrite the rows at *cursor (int64 CUDA scalar tensor) and advance it, all stream-ordered (graph-capturable)."""
+        if cursor.dtype != torch.int64 or not cursor.is_cuda or cursor.numel() != 1:
+            raise ValueError("cursor must be a 1-element int64 CUDA tensor")
+        with torch.cuda.device(self.device):
+            _ffi.check(self._lib.ivr_index_write_ring(self._h, C.c_void_p(rows.data_ptr()), rows.shape[0], int(bool(normalize)),
+                                                      C.c_void_p(cursor.data_ptr()), _ffi.stream_ptr()), "ivr_index_write_ring")
+
     def search(self, x, k):
         """(D, I) numpy arrays, exactly like faiss: D float32 [nq,k] descending, I int64 [nq,k], -1 padded."""
         q = np.asarray(x) if not isinstance(x, torch.Tensor) else x
