@@ -1080,6 +1080,111 @@ int ring_mode() {
     return v;
 }
 
+// Short-sequence variant (T <= 64: CLIP ViT-B/32 has T = 50): one key block, so no online-softmax state has to survive a
+// loop.  The K fragments of the head stay in registers (32) and the four 16-query tiles are processed one after the other
+// (S^T tile -> softmax -> P^T -> O^T tile -> store), which keeps the kernel at <= 128 VGPRs = 4 waves per SIMD: the kernel
+// is latency-bound (each wave touches 19 KB once), occupancy is what hides it.
+__global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsigned short *__restrict__ qkv,
+                                                                      unsigned short *__restrict__ att, int n, int Tn, int D, int heads,
+                                                                      int causal) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= (int64_t)n * heads) return;                 // waves are independent: no workgroup barrier below
+    const int h = (int)(item % heads), img = (int)(item / heads);
+    unsigned char *vt = smem + wave * VT_BYTES;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t rs = 3 * (int64_t)D;
+    const unsigned short *base = qkv + (int64_t)img * Tn * rs + h * 64;
+
+    // K fragments (A operand of S^T): key = 16*kt + c, dh = 32*ks + 8*g .. +7
+    uint4 kf[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const int key = min(kt * 16 + c, Tn - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[ks][kt] = *reinterpret_cast<const uint4 *>(base + D + key * rs + ks * 32 + g * 8);
+    }
+    // V^T -> LDS: lane owns key `lane`, scatters its 64 dh values down a column
+    {
+        const int key = min(lane, Tn - 1);
+        const uint4 *vp = reinterpret_cast<const uint4 *>(base + 2 * D + key * rs);
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const uint4 v = vp[ch];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<unsigned short *>(vt + (ch * 8 + 2 * i) * VT_STRIDE + lane * 2) = (unsigned short)(w[i] & 0xffffu);
+                *reinterpret_cast<unsigned short *>(vt + (ch * 8 + 2 * i + 1) * VT_STRIDE + lane * 2) = (unsigned short)(w[i] >> 16);
+            }
+        }
+    }
+    const int nqt = (Tn + 15) >> 4;
+#pragma unroll 1
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int q = qt * 16 + c;
+        const int qc = min(q, Tn - 1);
+        uint4 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const uint4 *>(base + qc * rs + ks * 32 + g * 8);
+        f32x4 s[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[0][kt]), __builtin_bit_cast(bf16x8_t, qf[0]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[1][kt]), __builtin_bit_cast(bf16x8_t, qf[1]), acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + g * 4 + r;
+                if (key >= Tn || (causal && key > q)) acc[r] = -INFINITY;
+                mx = fmaxf(mx, acc[r]);
+            }
+            s[kt] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = (s[kt][r] == -INFINITY) ? 0.f : __expf(s[kt][r] - mx);
+                s[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        uint4 pf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            pf[ks].x = ivr_pack_bf16x2(s[2 * ks][0], s[2 * ks][1]);
+            pf[ks].y = ivr_pack_bf16x2(s[2 * ks][2], s[2 * ks][3]);
+            pf[ks].z = ivr_pack_bf16x2(s[2 * ks + 1][0], s[2 * ks + 1][1]);
+            pf[ks].w = ivr_pack_bf16x2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
+        }
+        const float inv = 1.0f / sum;
+        unsigned short *op = att + ((int64_t)img * Tn + qc) * D + h * 64 + g * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char *row = vt + (nt * 16 + c) * VT_STRIDE + ks * 64 + g * 8;
+                const uint2 lo = *reinterpret_cast<const uint2 *>(row), hi = *reinterpret_cast<const uint2 *>(row + 32);
+                const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[ks]), o, 0, 0, 0);
+            }
+            if (q < Tn) {
+                const float v[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+                El<unsigned short>::store4(op + nt * 16, v);
+            }
+        }
+    }
+}
+
 template <typename T, int EPI, int ACT>
 int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
@@ -1202,6 +1307,13 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
     if (n <= 0) return IVR_OK;
     // FLOP: QK^T and PV, 2*T*T*64 each per (image, head)
     IvrProf prof("attention", s, 4.0 * n * heads * (double)T * T * 64);
+    if (!f32 && T <= 64) {
+        const int64_t items = (int64_t)n * heads;
+        hipLaunchKernelGGL(attention_mfma_short_kernel, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * VT_BYTES, s,
+                           (const unsigned short *)qkv, (unsigned short *)att, n, T, D, heads, causal);
+        IVR_LAUNCH_CHECK();
+        return IVR_OK;
+    }
     if (!f32) {
         const int nqb = (T + 63) / 64;
         const int64_t items = (int64_t)n * heads * nqb;
