@@ -19,6 +19,7 @@ struct GemmArgs {
     int T = 0, G2 = 0;             // tokens per image, patches per image
     int act = -1;                  // EPI_STORE: -1 none, else IVR_ACT_*
     const char *tag = nullptr;     // profiler name of this call site
+    int group_m = 8;               // row panels per L2-resident group (tile order of gemm_kernel)
 };
 
 int ivr_launch_gemm(bool f32, int epi, const GemmArgs &g, hipStream_t s);

@@ -198,14 +198,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: keeps the DMA addressing scalar
     const int wm = wave >> 1, wn = wave & 1;
     const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
-    // bijective XCD remap: workgroups b, b+8, b+16, ... share an XCD; give each XCD a contiguous id range
-    const int nwg = MT * NT;
-    int bid = blockIdx.x;
+    // Tile order.  Workgroups b, b+8, b+16, ... share an XCD (one L2).  XCD x owns the row panels p = x (mod 8); inside
+    // an XCD the panels are walked in groups of GROUP_M: a group's X panels (GROUP_M x 128 rows x K) stay in that L2 while
+    // its column tiles are swept, and neighbouring workgroups use the same W tile.
+    int tm, tn;
     {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;      // panels owned by this XCD
+        if (i >= lx * NT) return;
+        const int gm = g.group_m;
+        const int per = gm * NT, grp = i / per, within = i - grp * per;
+        const int gme = min(gm, lx - grp * gm);
+        tm = xcd + 8 * (grp * gm + within % gme);
+        tn = within / gme;
     }
-    const int tm = bid / NT, tn = bid % NT;
     const int m0 = tm * BM, n0 = tn * BN;
     constexpr int EPR = ROWB / (int)sizeof(T);   // elements of K per step
     const int KT = g.K / EPR;
@@ -1256,7 +1262,15 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, EPI, ACT>), dim3(MT * NT), dim3(256), GEMM_LDS, s, g);
+    GemmArgs ga = g;
+    static int group_m = -1;
+    if (group_m < 0) {
+        const char *e = getenv("IVR_GEMM_GROUP_M");
+        group_m = e ? std::max(1, atoi(e)) : 8;
+    }
+    ga.group_m = group_m;
+    const int grid = 8 * ((MT + 7) / 8) * NT;               // every XCD gets the same number of ids; surplus ones exit
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, ACT>), dim3(grid), dim3(256), GEMM_LDS, s, ga);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
