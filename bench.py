@@ -71,9 +71,9 @@ def cpu_baseline(cfg, weights, frames_u8, index_rows, queries, k, budget_s=20.0)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=49)           # 49 x 2048 = 100,352 frames (configs[1]: 100k)
+    ap.add_argument("--steps", type=int, default=25)           # 25 x 4096 = 102,400 frames (configs[1]: 100k)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=2048)
+    ap.add_argument("--frames-per-step", type=int, default=4096)
     ap.add_argument("--index-rows", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=10)
     ap.add_argument("--k", type=int, default=10)
@@ -183,7 +183,7 @@ def main():
                 pmc = json.load(f)
         except OSError:
             pass
-        pmc_ok = B == 2048 and N == 1_000_000
+        pmc_ok = B == pmc.get("_frames_per_step", -1) and N == 1_000_000
 
         def traffic(*kernels):
             if not pmc_ok or not all(k in pmc for k in kernels):

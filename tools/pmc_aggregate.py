@@ -33,11 +33,14 @@ def agg(path):
     return d
 
 
-def main(src, dst):
+def main(src, dst, frames_per_step=4096):
     f = agg(glob.glob(f"{src}/fetch/*/*_counter_collection.csv")[0])
     w = agg(glob.glob(f"{src}/write/*/*_counter_collection.csv")[0])
-    out = {"_note": "per-launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction)"}
+    out = {"_note": "per-launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction)",
+           "_frames_per_step": frames_per_step}
     for k in sorted(f):
+        if k.startswith("_"):
+            continue
         n = f[k][0]
         fk = f[k][1] / n
         wk = w[k][1] / max(1, w[k][0]) if k in w else 0.0
@@ -48,4 +51,4 @@ def main(src, dst):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 4096)
