@@ -362,6 +362,192 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// GEMM, large-tile version: 256 x 256 tile, 8 waves as 2(m) x 4(n), each wave 128 x 64 = 8 x 4 MFMA tiles.
+// Same staging scheme as gemm_kernel (two LDS buffers of 64 KiB filled by buffer_load ... lds, swizzled source, asm
+// fragment reads), but half the operand bytes per FLOP (what the DMA has to keep in flight to cover its latency), 0.375
+// instead of 0.5 fragment reads per MFMA, and a quarter of the tile prologues / epilogues per FLOP.  One workgroup per
+// CU (128 KiB of LDS), two waves per SIMD.
+// ---------------------------------------------------------------------------------------------
+constexpr int LBM = 256, LBN = 256, LX_BYTES = LBM * ROWB, LW_BYTES = LBN * ROWB, LSTAGE = LX_BYTES + LW_BYTES;
+constexpr int BIG_LDS = 2 * LSTAGE;   // 128 KiB
+
+template <typename T, int EPI, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
+    int tm, tn;
+    {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;
+        if (i >= lx * NT) return;
+        const int gm = g.group_m;
+        const int per = gm * NT, grp = i / per, within = i - grp * per;
+        const int gme = min(gm, lx - grp * gm);
+        tm = xcd + 8 * (grp * gm + within % gme);
+        tn = within / gme;
+    }
+    const int m0 = tm * LBM, n0 = tn * LBN;
+    constexpr int EPR = ROWB / (int)sizeof(T);
+    const int KT = g.K / EPR;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // 32 + 32 pieces of 1 KiB per stage; wave w issues pieces 4w .. 4w+3 of X and of W
+    unsigned voffX[4], voffW[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (wave * 4 + j) + (lane >> 3), c = (lane & 7) ^ (lane >> 3);
+        voffX[j] = (unsigned)(r * g.lda) * (unsigned)sizeof(T) + c * 16;
+        voffW[j] = (unsigned)(r * g.ldw) * (unsigned)sizeof(T) + c * 16;
+    }
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.A), 0, (int)((int64_t)g.M * g.lda * sizeof(T)), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * sizeof(T)), 0x00020000);
+    const unsigned sx0 = (unsigned)m0 * (unsigned)g.lda * (unsigned)sizeof(T), sw0 = (unsigned)n0 * (unsigned)g.ldw * (unsigned)sizeof(T);
+    auto stage = [&](int kt, int buf) {
+        unsigned char *base = smem + buf * LSTAGE + (wave * 4) * 1024;
+        const unsigned adv = (unsigned)kt * ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + j * 1024), 16, voffX[j],
+                                                     sx0 + adv, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + LX_BYTES + j * 1024), 16,
+                                                     voffW[j], sw0 + adv, 0, 0);
+        }
+    };
+    unsigned foX[2], foW[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const unsigned f = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+        foX[kk] = lds0 + (wm * 128) * ROWB + f;
+        foW[kk] = lds0 + LX_BYTES + (wn * 64) * ROWB + f;
+    }
+
+    f32x4 acc[4][8];   // [nt][mt]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define IVR_BIG_READ(KK)                                                                                   \
+    {                                                                                                      \
+        const unsigned xa = foX[KK] + boff, wa = foW[KK] + boff;                                           \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(wa));                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(wf[2]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(wf[3]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(xf[0]) : "v"(xa));                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(xf[1]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(xf[2]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(xf[3]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(xf[4]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(xf[5]) : "v"(xa));                          \
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(xf[6]) : "v"(xa));                          \
+        asm volatile("ds_read_b128 %0, %1 offset:14336" : "=v"(xf[7]) : "v"(xa));                          \
+    }
+
+    stage(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+        const unsigned boff = (kt & 1) * LSTAGE;
+        u32x4 xf[8], wf[4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 0) IVR_BIG_READ(0) else IVR_BIG_READ(1)
+            // the first four W/X fragments are enough to start: the MFMAs below consume xf[0..3] first
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) mma_chunk<T>(wf[nt], xf[mt], acc[nt][mt]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 4; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) mma_chunk<T>(wf[nt], xf[mt], acc[nt][mt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef IVR_BIG_READ
+
+    // epilogue in two halves of four row tiles (keeps the batched residual loads at 64 registers)
+    int ncol[4];
+    bool nok[4];
+    float4 bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ncol[t] = n0 + wn * 64 + t * 16 + 4 * (lane >> 4);
+        nok[t] = ncol[t] < g.N;
+        ncol[t] = min(ncol[t], g.N - 4);
+        bv[t] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + ncol[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int mrow[4];
+        bool mok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            mrow[t] = m0 + wm * 128 + (half * 4 + t) * 16 + (lane & 15);
+            mok[t] = mrow[t] < g.M;
+            mrow[t] = min(mrow[t], g.M - 1);
+        }
+        if (EPI == EPI_RESID || EPI == EPI_PATCH) {
+            float4 rv[4][4];
+            float *rowp[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (EPI == EPI_RESID) {
+                    rowp[mt] = g.resid + (int64_t)mrow[mt] * g.ldr;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) rv[mt][nt] = *reinterpret_cast<const float4 *>(rowp[mt] + ncol[nt]);
+                } else {
+                    const int img = mrow[mt] / g.G2, pch = mrow[mt] % g.G2;
+                    rowp[mt] = g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        rv[mt][nt] = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol[nt]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float4 r = rv[mt][nt];
+                    const f32x4 a = acc[nt][half * 4 + mt];
+                    r.x += a[0] + bv[nt].x;
+                    r.y += a[1] + bv[nt].y;
+                    r.z += a[2] + bv[nt].z;
+                    r.w += a[3] + bv[nt].w;
+                    if (mok[mt] && nok[nt]) *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f32x4 a = acc[nt][half * 4 + mt];
+                    float v[4] = {a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w};
+                    if (ACT >= 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
+                    }
+                    if (mok[mt] && nok[nt]) {
+                        if (EPI == EPI_STORE)
+                            El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt], v);
+                        else
+                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt]) =
+                                make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // GEMM, ring version (production): 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), persistent workgroups (one per CU)
 // that walk a list of tiles, and ONE continuous LDS-DMA ring of 3 stages (48 KiB each: X 256 rows + W 128 rows of
 // 128 B) running two K steps ahead of the MFMAs - across tile boundaries too, so a tile's first stages land under
@@ -1074,14 +1260,15 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
     }
 }
 
-// kernel choice, overridable for A/B runs: IVR_GEMM=0 one-tile-per-workgroup 128x128 kernel, 1 persistent 128x128
+// kernel choice, overridable for A/B runs (default: 4 for large problems, else 0): IVR_GEMM=0 128x128 kernel, 4 256x256
+// kernel, 1 persistent 128x128
 // (2 stages, 2 workgroups per CU), 2 persistent 256x128 (3 stages, 1 workgroup per CU), 3 stream kernel (4-stage ring,
 // counted waits, one 4-wave workgroup per CU)
 int ring_mode() {
-    static int v = -1;
-    if (v < 0) {
+    static int v = -2;
+    if (v == -2) {
         const char *e = getenv("IVR_GEMM");
-        v = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0;
+        v = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : -1;
     }
     return v;
 }
@@ -1194,7 +1381,29 @@ __global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsi
 template <typename T, int EPI, int ACT>
 int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
-    const int mode = ring_mode();
+    int mode = ring_mode();
+    // default (-1): the 256 x 256 kernel once it fills the chip, the 128 x 128 kernel for small problems
+    if (mode < 0) mode = ((g.M + LBM - 1) / LBM) * ((g.N + LBN - 1) / LBN) >= 192 ? 4 : 0;
+    if (mode == 4) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS));
+            attr_done = true;
+        }
+        GemmArgs ga = g;
+        static int group_m = -1;
+        if (group_m < 0) {
+            const char *e = getenv("IVR_GEMM_GROUP_M");
+            group_m = e ? std::max(1, atoi(e)) : 0;
+        }
+        const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
+        ga.group_m = group_m ? group_m : (NT <= 3 ? 2 : 8);     // measured: narrow outputs want short groups
+        const int grid = 8 * ((MT + 7) / 8) * NT;
+        hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT>), dim3(grid), dim3(512), BIG_LDS, s, ga);
+        IVR_LAUNCH_CHECK();
+        return IVR_OK;
+    }
     // the stream kernel needs >= 4 K steps per tile, outputs below 2 GiB (32-bit buffer offsets) and enough tiles
     const int64_t out_bytes = (int64_t)g.M * std::max(g.ldo, g.ldr) * 4;
     const int kt_steps = g.K / (ROWB / (int)sizeof(T));
