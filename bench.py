@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--queries", type=int, default=10)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1, help="split each step's frames over this many HIP streams / towers")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,7 +114,11 @@ def main():
     cfg = C.CLIP_VIT_B32
     B, N, Q, k = args.frames_per_step, args.index_rows, args.queries, args.k
     weights = make_weights(cfg, 12)
-    tower = Tower(cfg, weights, max_batch=B, compute="bf16", device=local_rank)
+    L = max(1, args.lanes)
+    assert B % L == 0
+    towers = [Tower(cfg, weights, max_batch=B // L, compute="bf16", device=local_rank) for _ in range(L)]
+    tower = towers[0]
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(L)] if L > 1 else [None]
 
     # synthetic inputs, generated on the device (a 100k-frame host array would be 15 GB)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -134,11 +139,27 @@ def main():
     ring = {"pos": 0}
     ev_s0, ev_s1 = [], []
 
+    def embed(lane, i, pos):
+        b = B // L
+        fr = frame_tiles[i & 1][lane * b:(lane + 1) * b]
+        pt = patches[lane * b * 49:(lane + 1) * b * 49]
+        em = emb[lane * b:(lane + 1) * b]
+        preprocess_frames(fr, "identity", C.CLIP_MEAN, C.CLIP_STD, size=224, patch=32, out=pt)
+        towers[lane].encode_patches(pt, b, normalize=True, out=em)
+        index.write_device(pos + lane * b, em)          # rows are already L2-normalised by the tower epilogue
+
     def step(i, timed):
-        preprocess_frames(frame_tiles[i & 1], "identity", C.CLIP_MEAN, C.CLIP_STD, size=224, patch=32, out=patches)
-        tower.encode_patches(patches, B, normalize=True, out=emb)
         pos = ring["pos"]
-        index.write_device(pos, emb)          # rows are already L2-normalised by the tower epilogue
+        if L == 1:
+            embed(0, i, pos)
+        else:
+            main = torch.cuda.current_stream()
+            for lane in range(L):
+                lanes[lane].wait_stream(main)
+                with torch.cuda.stream(lanes[lane]):
+                    embed(lane, i, pos)
+            for lane in range(L):
+                main.wait_stream(lanes[lane])
         ring["pos"] = (pos + B) % (N - B + 1) if N > B else 0
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

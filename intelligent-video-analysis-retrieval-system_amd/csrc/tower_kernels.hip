@@ -430,48 +430,50 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#define IVR_BIG_READ(KK)                                                                                   \
+#define IVR_BIG_READ(KK, XF, WF)                                                                           \
     {                                                                                                      \
         const unsigned xa = foX[KK] + boff, wa = foW[KK] + boff;                                           \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[0]) : "v"(wa));                                       \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[1]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(wf[2]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(wf[3]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(xf[0]) : "v"(xa));                                       \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(xf[1]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(xf[2]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(xf[3]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(xf[4]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(xf[5]) : "v"(xa));                          \
-        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(xf[6]) : "v"(xa));                          \
-        asm volatile("ds_read_b128 %0, %1 offset:14336" : "=v"(xf[7]) : "v"(xa));                          \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(WF[0]) : "v"(wa));                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(WF[1]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(WF[2]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(WF[3]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(XF[0]) : "v"(xa));                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(XF[1]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(XF[2]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(XF[3]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(XF[4]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(XF[5]) : "v"(xa));                          \
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(XF[6]) : "v"(xa));                          \
+        asm volatile("ds_read_b128 %0, %1 offset:14336" : "=v"(XF[7]) : "v"(xa));                          \
     }
+#define IVR_BIG_MMA(XF, WF, LO)                                                                            \
+    _Pragma("unroll") for (int mt = LO; mt < LO + 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) \
+        mma_chunk<T>(WF[nt], XF[mt], acc[nt][mt]);
+#define IVR_BIG_WAIT(N)                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);
 
     stage(0, 0);
     for (int kt = 0; kt < KT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
         const unsigned boff = (kt & 1) * LSTAGE;
-        u32x4 xf[8], wf[4];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 0) IVR_BIG_READ(0) else IVR_BIG_READ(1)
-            // the first four W/X fragments are enough to start: the MFMAs below consume xf[0..3] first
-            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) mma_chunk<T>(wf[nt], xf[mt], acc[nt][mt]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 4; mt < 8; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) mma_chunk<T>(wf[nt], xf[mt], acc[nt][mt]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // two fragment sets: the 12 reads of the second half-step are issued under the first half-step's MFMAs
+        u32x4 xa0[8], wa0[4], xa1[8], wa1[4];
+        IVR_BIG_READ(0, xa0, wa0)
+        IVR_BIG_WAIT(4)                 // W + first four X fragments of set 0
+        IVR_BIG_MMA(xa0, wa0, 0)
+        IVR_BIG_READ(1, xa1, wa1)
+        IVR_BIG_WAIT(12)                // all of set 0 (set 1 still in flight)
+        IVR_BIG_MMA(xa0, wa0, 4)
+        IVR_BIG_WAIT(4)
+        IVR_BIG_MMA(xa1, wa1, 0)
+        IVR_BIG_WAIT(0)
+        IVR_BIG_MMA(xa1, wa1, 4)
+        __builtin_amdgcn_sched_barrier(0);
     }
+#undef IVR_BIG_MMA
+#undef IVR_BIG_WAIT
 #undef IVR_BIG_READ
 
     // epilogue in two halves of four row tiles (keeps the batched residual loads at 64 registers)
