@@ -192,3 +192,16 @@ def test_baseline_config2_full_size(nq):
     rows = torch.from_numpy(X[[0, 123_456, 999_999]]).cuda()
     D2, I2 = idx.search_device(rows, 1)
     assert I2.flatten().tolist() == [0, 123_456, 999_999] and (D2 - 1).abs().max() < 1e-5
+
+
+def test_baseline_config3_shape_many_queries():
+    """BASELINE config 3 per-GPU shape scaled down in N: a 1000-query batch, top-10, against the oracle (the index is read
+    once per 64 queries)."""
+    rng = np.random.default_rng(31)
+    X = S.normalize_rows_core(rng.standard_normal((30_000, 512), dtype=np.float32)).astype(np.float32)
+    Q = rng.standard_normal((1000, 512), dtype=np.float32)
+    idx = _index(X)
+    D, I = idx.search_device(Q, 10, normalize=True)
+    Dr, Ir = S.flat_ip_search(X, S.normalize_rows_core(Q).astype(np.float32), 10, dtype=np.float64)
+    assert np.array_equal(I.cpu().numpy(), Ir)
+    assert np.abs(D.cpu().numpy() - Dr).max() < 1e-5
