@@ -185,6 +185,11 @@ int ivr_topk_merge(ivr_ctx *ctx, const float *D_parts /*DEV*/, const int64_t *I_
 int ivr_dedup_keep_mask(ivr_ctx *ctx, const float *emb /*DEV*/, int n, int d, float threshold,
                         float *state /*DEV*/, uint8_t *keep /*DEV*/, ivr_stream stream);
 
+/* cos(a[i], b[i]) for i < n (DEV float32 [n,d] each), sklearn cosine_similarity conventions.  Replaces the per-pair
+ * cosine_similarity([x],[y])[0][0] calls of the keyframe filter (filter.py:147, filter.py:208). */
+int ivr_rowwise_cosine(ivr_ctx *ctx, const float *a /*DEV*/, const float *b /*DEV*/, int n, int d, float *out /*DEV*/,
+                       ivr_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

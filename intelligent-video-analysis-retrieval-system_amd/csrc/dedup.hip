@@ -51,7 +51,38 @@ __global__ __launch_bounds__(64) void dedup_kernel(const float *__restrict__ emb
     }
 }
 
+// cos(a[i], b[i]) with sklearn's conventions (each row divided by its norm, zero norm -> 1): one wave per row pair
+__global__ __launch_bounds__(256) void rowwise_cosine_kernel(const float *__restrict__ a, const float *__restrict__ b, int n, int d,
+                                                             float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *pa = a + (int64_t)row * d, *pb = b + (int64_t)row * d;
+    float dot = 0.f, sa = 0.f, sb = 0.f;
+    for (int k = lane; k < d; k += 64) {
+        const float x = pa[k], y = pb[k];
+        dot = fmaf(x, y, dot);
+        sa = fmaf(x, x, sa);
+        sb = fmaf(y, y, sb);
+    }
+    dot = ivr_wave_sum(dot);
+    sa = ivr_wave_sum(sa);
+    sb = ivr_wave_sum(sb);
+    const float na = sa > 0.f ? sqrtf(sa) : 1.f, nb = sb > 0.f ? sqrtf(sb) : 1.f;
+    if (lane == 0) out[row] = dot / (na * nb);
+}
+
 }  // namespace
+
+extern "C" int ivr_rowwise_cosine(ivr_ctx *ctx, const float *a, const float *b, int n, int d, float *out, ivr_stream stream) {
+    IVR_REQUIRE(ctx && (n == 0 || (a && b && out)), "ivr_rowwise_cosine: NULL argument");
+    IVR_REQUIRE(n >= 0 && d >= 1, "ivr_rowwise_cosine: n=%d d=%d", n, d);
+    if (n == 0) return IVR_OK;
+    IVR_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(rowwise_cosine_kernel, dim3((unsigned)ivr_ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, a, b, n, d, out);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
 
 extern "C" int ivr_dedup_keep_mask(ivr_ctx *ctx, const float *emb, int n, int d, float threshold, float *state,
                                    uint8_t *keep, ivr_stream stream) {

@@ -374,6 +374,49 @@ class FAISSRetriever:
                         results.append(SearchResult(metadata=md, similarity_score=s, rank=rank + 1, query_relevance=s))
             return results
 
+    def save_index(self, index_path: str, validate_before_save: bool = True) -> None:
+        """core.py:960: <index_path>/index.faiss (flat FAISS container, ivr_amd.faiss_io) + metadata.json."""
+        if not self.is_trained:
+            raise RuntimeError("Cannot save untrained index")
+        if validate_before_save and self.index.ntotal != len(self.id_to_metadata):
+            raise RuntimeError("Cannot save inconsistent index: index size != metadata count")
+        from .faiss_io import write_flat_index
+        os.makedirs(index_path, exist_ok=True)
+        write_flat_index(os.path.join(index_path, "index.faiss"), self.index.reconstruct_n(0, self.index.ntotal), "ip")
+        meta = {"version": "2.1", "created_at": time.time(),
+                "id_to_metadata": {str(k): v.to_dict() for k, v in self.id_to_metadata.items()},
+                "metadata_to_id": dict(self.metadata_to_id), "next_id": self.next_id, "dimension": self.dimension,
+                "index_type": self.index_type, "is_trained": self.is_trained, "index_size": self.index.ntotal}
+        tmp = os.path.join(index_path, "metadata.json.tmp")
+        with open(tmp, "w", encoding="utf-8") as f:
+            json.dump(meta, f, indent=2, ensure_ascii=False)
+        os.replace(tmp, os.path.join(index_path, "metadata.json"))
+
+    def load_index(self, index_path: str, validate_after_load: bool = True) -> None:
+        """core.py:1041: the rows go straight into HBM (no FAISS object is rebuilt)."""
+        from .faiss_io import read_flat_index
+        ff = os.path.join(index_path, "index.faiss")
+        if not os.path.exists(ff):
+            raise FileNotFoundError(f"Index file not found: {ff}")
+        mf = os.path.join(index_path, "metadata.json")
+        if not os.path.exists(mf):
+            raise FileNotFoundError(f"Metadata file not found: {mf}")
+        vectors, _ = read_flat_index(ff)
+        with open(mf, encoding="utf-8") as f:
+            meta = json.load(f)
+        with self._lock:
+            self.id_to_metadata = {int(k): KeyframeMetadata.from_dict(v) for k, v in meta["id_to_metadata"].items()}
+            self.metadata_to_id = dict(meta.get("metadata_to_id", {}))
+            self.next_id = int(meta.get("next_id", len(self.id_to_metadata)))
+            self.dimension = vectors.shape[1]
+            self.index = FlatIPIndex(self.dimension, capacity=len(vectors))
+            self.index.add(vectors)                          # stored rows are already normalised (core.py:809-827)
+            self.is_trained = True
+            if validate_after_load and self.index.ntotal != len(self.id_to_metadata):
+                self.index, self.is_trained = None, False
+                raise RuntimeError("Index and metadata are inconsistent. This suggests the system was not properly built or "
+                                   "saved. Please rebuild the system from keyframes.")
+
     def search_by_id(self, metadata_key: str, k: int = 10):
         if metadata_key not in self.metadata_to_id:
             return []

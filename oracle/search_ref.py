@@ -170,3 +170,40 @@ def merge_shards(D_parts, I_parts, k):
         D[q, :len(order)] = d[order]
         I[q, :len(order)] = i[order]
     return D, I
+
+
+# ---- adjacent consumers -------------------------------------------------------------------
+def consecutive_similarities(embeddings):
+    """filter.py:142-150."""
+    return [cosine_1x1(embeddings[i - 1], embeddings[i]) for i in range(1, len(embeddings))]
+
+
+def filter_similar_frames_in_scene(scene_embeddings, scene_indices, config):
+    """filter.py:178-222, line by line."""
+    if not config["enable_similarity_filtering"] or len(scene_embeddings) <= 1:
+        return scene_indices
+    thr, min_distance = config["similarity_threshold"], config["min_frame_distance"]
+    kept, last = [0], 0
+    for i in range(1, len(scene_embeddings)):
+        if i - last < min_distance:
+            continue
+        if cosine_1x1(scene_embeddings[i], scene_embeddings[last]) < thr:
+            kept.append(i)
+            last = i
+    if kept[-1] != len(scene_embeddings) - 1:
+        kept.append(len(scene_embeddings) - 1)
+    return [scene_indices[i] for i in kept]
+
+
+def similarity_graph(features, keys, top=10, threshold=0.7):
+    """core.py:3513-3526 with sklearn's cosine_similarity restated (row-normalise, then X X^T)."""
+    f = np.asarray(features, dtype=np.float64)
+    n = np.linalg.norm(f, axis=1, keepdims=True)
+    n[n == 0] = 1
+    f = f / n
+    sim = f @ f.T
+    out = {}
+    for i, key in enumerate(keys):
+        order = np.argsort(sim[i])[::-1][1:top + 1]
+        out[key] = [keys[j] for j in order if sim[i][j] > threshold]
+    return out

@@ -163,3 +163,32 @@ def test_frame_filter_dedup_pipeline():
     r = V.vision_forward(cfg, w, P.preprocess([np.asarray(Image.fromarray(base[0]).resize((224, 224)))], "identity",
                                               C.IMAGENET_MEAN, C.IMAGENET_STD), normalize=False)[0]
     assert e.shape == (384,) and np.abs(e - r).max() / np.abs(r).max() < 1e-4
+
+
+def test_legacy_save_load_and_threaded_encode(extractor, keyframes, tmp_path):
+    """core.py:960/1041 persistence round trip, and the reference's 4-thread batch-1 encode pattern
+    (unified_index.py:773-828) against one extractor."""
+    from concurrent.futures import ThreadPoolExecutor
+    from ivr_amd.compat import FAISSRetriever
+    root, paths = keyframes
+    for junk in ("bad.jpg", "tiny.jpg"):
+        if os.path.exists(os.path.join(root, "L01_V000", junk)):
+            os.remove(os.path.join(root, "L01_V000", junk))
+    feats, metas = extractor.extract_features_batch(root)
+    r = FAISSRetriever()
+    with pytest.raises(RuntimeError):
+        r.save_index(str(tmp_path / "legacy"))
+    r.build_index(feats, metas)
+    r.save_index(str(tmp_path / "legacy"))
+    assert sorted(os.listdir(tmp_path / "legacy")) == ["index.faiss", "metadata.json"]
+    r2 = FAISSRetriever()
+    with pytest.raises(FileNotFoundError):
+        r2.load_index(str(tmp_path / "nope"))
+    r2.load_index(str(tmp_path / "legacy"))
+    a, b = r.search(feats[3], k=4), r2.search(feats[3], k=4)
+    assert [(x.rank, x.metadata.get_unique_key()) for x in a] == [(x.rank, x.metadata.get_unique_key()) for x in b]
+    # reloaded clip_features come back from JSON as float64 (KeyframeMetadata.from_dict, core.py:146-151)
+    assert np.allclose([x.similarity_score for x in a], [x.similarity_score for x in b], atol=1e-5)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        single = list(ex.map(lambda p: extractor.encode_images([p], show_progress=False)[0], sorted(paths)))
+    assert ((np.stack(single) * feats).sum(1) > 1 - 1e-6).all()         # same rows as the batched call

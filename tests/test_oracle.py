@@ -124,3 +124,23 @@ def test_merge_shards_equals_global_search():
                    for a, b in parts])
     Dm, Im = S.merge_shards(Dp, Ip, 10)
     assert np.array_equal(Im, I) and np.array_equal(Dm, D)
+
+
+def test_faiss_flat_container_round_trip(tmp_path):
+    """Layout restated from faiss's serialiser (UNPINNED: faiss is absent); the header must be the 45 packed bytes the
+    docstring lists and the payload must round-trip bit-exactly."""
+    from ivr_amd import faiss_io
+    x = np.random.default_rng(0).standard_normal((37, 24)).astype(np.float32)
+    p = tmp_path / "index.faiss"
+    faiss_io.write_flat_index(str(p), x)
+    raw = p.read_bytes()
+    assert raw[:4] == b"IxFI" and len(raw) == 45 + x.nbytes
+    assert int.from_bytes(raw[4:8], "little") == 24 and int.from_bytes(raw[8:16], "little") == 37
+    y, metric = faiss_io.read_flat_index(str(p))
+    assert metric == "ip" and np.array_equal(x, y)
+    p.write_bytes(b"IwFl" + raw[4:])
+    with pytest.raises(ValueError):
+        faiss_io.read_flat_index(str(p))
+    p.write_bytes(raw[:-8])
+    with pytest.raises(ValueError):
+        faiss_io.read_flat_index(str(p))
