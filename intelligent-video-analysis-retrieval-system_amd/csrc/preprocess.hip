@@ -274,12 +274,14 @@ struct Out8<float> {
     static __device__ __forceinline__ void store1(float *p, float v) { *p = v; }
 };
 
-// vector path: P % 8 == 0, R rows per workgroup with R | P or P | R
-template <typename T>
+// vector path: P % 8 == 0, R rows per workgroup with R | P or P | R.  PC > 0 fixes P = R = PC at compile time so that the
+// (patch column, channel, row, 8-pixel group) decomposition of a work item is shifts and constant divisions: with run-time
+// P the integer divisions cost more VALU time than the bytes cost HBM time (measured 34 % -> see profiles/).
+template <typename T, int PC>
 __global__ __launch_bounds__(256) void emit_vec_kernel(const uint8_t *__restrict__ src, T *__restrict__ dst,
                                                        const float *__restrict__ lut, EmitParams ep) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lines[];
-    const int S = ep.S, P = ep.P, R = ep.R;
+    const int S = ep.S, P = PC > 0 ? PC : ep.P, R = PC > 0 ? PC : ep.R;
     float *slut = reinterpret_cast<float *>(lines + (((size_t)R * S * 3 + 15) & ~(size_t)15));
     const int blocks_per_frame = S / R;
     const int f = blockIdx.x / blocks_per_frame, rb = blockIdx.x % blocks_per_frame;
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(256) void emit_vec_kernel(const uint8_t *__restrict
     const int G = S / P;                 // patches per side
     const int xs_n = P / 8;              // 8-element groups per patch line
     const int ngroups = G * 3 * R * xs_n;
+    const float a0 = ep.a[0], a1 = ep.a[1], a2 = ep.a[2], b0 = ep.b[0], b1 = ep.b[1], b2 = ep.b[2];
     for (int g = threadIdx.x; g < ngroups; g += blockDim.x) {
         int r = g;
         const int xs = r % xs_n;
@@ -305,11 +308,12 @@ __global__ __launch_bounds__(256) void emit_vec_kernel(const uint8_t *__restrict
         const int y = y0 + yy;
         const int cc = ep.bgr ? 2 - c : c;
         const uint8_t *lp = lines + ((yy * S) + px * P + xs * 8) * 3 + cc;
+        const float sa = c == 0 ? a0 : (c == 1 ? a1 : a2), sb = c == 0 ? b0 : (c == 1 ? b1 : b2);
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int u = lp[i * 3];
-            v[i] = ep.use_lut ? slut[c * 256 + u] : fmaf((float)u, ep.a[c], ep.b[c]);
+            v[i] = ep.use_lut ? slut[c * 256 + u] : fmaf((float)u, sa, sb);
         }
         const int64_t patch = ((int64_t)f * G + y / P) * G + px;
         Out8<T>::store(dst + patch * ep.Kpad + (c * P + (y % P)) * P + xs * 8, v);
@@ -470,11 +474,14 @@ int ivr_preprocess(ivr_ctx *ctx, const uint8_t *src, int n, int h, int w, int fl
         IVR_REQUIRE(S % ep.R == 0, "ivr_preprocess: out_size %d not divisible by row block %d", S, ep.R);
         const size_t lds = (((size_t)ep.R * S * 3 + 15) & ~(size_t)15) + 768 * 4;
         const unsigned grid = (unsigned)((int64_t)n * (S / ep.R));
-        if (f32_out)
-            hipLaunchKernelGGL(emit_vec_kernel<float>, dim3(grid), dim3(256), lds, s, canvas, (float *)dst, d_lut, ep);
-        else
-            hipLaunchKernelGGL(emit_vec_kernel<unsigned short>, dim3(grid), dim3(256), lds, s, canvas, (unsigned short *)dst, d_lut,
-                               ep);
+#define IVR_EMIT(TT, PCV) \
+    hipLaunchKernelGGL((emit_vec_kernel<TT, PCV>), dim3(grid), dim3(256), lds, s, canvas, (TT *)dst, d_lut, ep)
+        if (f32_out) {
+            if (P == 32) IVR_EMIT(float, 32); else if (P == 16) IVR_EMIT(float, 16); else IVR_EMIT(float, 0);
+        } else {
+            if (P == 32) IVR_EMIT(unsigned short, 32); else if (P == 16) IVR_EMIT(unsigned short, 16); else IVR_EMIT(unsigned short, 0);
+        }
+#undef IVR_EMIT
     } else {
         const int G = S / P;
         const int64_t total = (int64_t)n * G * G * ep.Kpad;

@@ -302,6 +302,8 @@ struct SrcParts {      // shard merge: candidate p = part*k + j; ties resolve to
 
 enum { OUT_GROUPS = 0, OUT_DI = 1, OUT_DI_PARTS = 2 };
 
+constexpr int kRegKeys = 16;   // keys cached per thread: n <= 16 * 1024 is selected without re-reading global memory
+
 template <typename Src, int OUT>
 __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int qcol0, int k, int64_t id_base,
                                                                   uint32_t *__restrict__ out_groups,
@@ -314,19 +316,69 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
     const int q = blockIdx.x;
     const int qsrc = qcol0 + q;
     const int tid = threadIdx.x;
+    const int nthr = blockDim.x;          // 256 for short candidate lists (cheaper barriers), else 1024
     const int64_t n = src.n;
+    // The candidate keys of one query are few (N/64 group maxima, or k*64 rescored rows): keep them in registers so
+    // that the eight radix passes cost LDS histogram time only, not eight dependent trips to L2.
+    const bool cached = n <= (int64_t)kRegKeys * nthr;
+    uint64_t kreg[kRegKeys];
+    if (cached) {
+#pragma unroll
+        for (int j = 0; j < kRegKeys; ++j) {
+            const int64_t i = (int64_t)j * nthr + tid;
+            kreg[j] = i < n ? src.key(qsrc, i) : 0;
+        }
+    }
+    auto for_each_key = [&](auto &&fn) {
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < kRegKeys; ++j) fn(kreg[j]);
+        } else {
+            for (int64_t i = tid; i < n; i += nthr) fn(src.key(qsrc, i));
+        }
+    };
 
     // count valid keys (key 0 = absent)
     if (tid == 0) s_valid = 0;
     __syncthreads();
     {
         unsigned int c = 0;
-        for (int64_t i = tid; i < n; i += kSelThreads) c += src.key(qsrc, i) != 0;
+        for_each_key([&](uint64_t key) { c += key != 0; });
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
         if ((tid & 63) == 0 && c) atomicAdd(&s_valid, c);
     }
     __syncthreads();
     const unsigned int keff = min((unsigned int)k, s_valid);
+    if (cached && keff <= 64) {
+        // Small k (the reference asks for 10..50): extract the maximum keff times.  Per round: 16 register compares, a
+        // wave max by shuffles, one LDS word per wave, two barriers - a few hundred cycles, against radix passes whose LDS
+        // histogram atomics all collide on one bin when the scores share their leading bits.
+        __shared__ uint64_t wmax[kSelThreads / 64];
+        for (unsigned int it = 0; it < keff; ++it) {
+            uint64_t m = 0;
+#pragma unroll
+            for (int j = 0; j < kRegKeys; ++j) m = kreg[j] > m ? kreg[j] : m;
+            uint64_t wm = m;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t hi = __shfl_xor((uint32_t)(wm >> 32), o, 64), lo = __shfl_xor((uint32_t)wm, o, 64);
+                const uint64_t other = ((uint64_t)hi << 32) | lo;
+                wm = other > wm ? other : wm;
+            }
+            if ((tid & 63) == 0) wmax[tid >> 6] = wm;
+            __syncthreads();
+            uint64_t gm = 0;
+#pragma unroll
+            for (int w = 0; w < kSelThreads / 64; ++w) gm = (w < (nthr >> 6) && wmax[w] > gm) ? wmax[w] : gm;
+            if (tid == 0) sorted[it] = gm;
+            if (m == gm) {                     // keys are unique: exactly one thread owns it
+#pragma unroll
+                for (int j = 0; j < kRegKeys; ++j)
+                    if (kreg[j] == gm) kreg[j] = 0;
+            }
+            __syncthreads();
+        }
+    } else {
     uint64_t tau = ~0ull;   // nothing selected when keff == 0
     if (keff > 0) {
         if (tid == 0) {
@@ -339,10 +391,9 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const unsigned long long prefix = s_prefix, mask = s_mask;
-            for (int64_t i = tid; i < n; i += kSelThreads) {
-                const uint64_t key = src.key(qsrc, i);
+            for_each_key([&](uint64_t key) {
                 if (key != 0 && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
-            }
+            });
             __syncthreads();
             if (tid == 0) {
                 unsigned int kth = s_kth, cum = 0;
@@ -367,21 +418,20 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
     int P = 1;
     while (P < (int)keff) P <<= 1;
     if (tid == 0) s_cnt = 0;
-    for (int i = tid; i < P; i += kSelThreads) sorted[i] = 0;
+    for (int i = tid; i < P; i += nthr) sorted[i] = 0;
     __syncthreads();
     if (keff > 0) {
-        for (int64_t i = tid; i < n; i += kSelThreads) {
-            const uint64_t key = src.key(qsrc, i);
+        for_each_key([&](uint64_t key) {
             if (key != 0 && key >= tau) {
                 const unsigned int slot = atomicAdd(&s_cnt, 1u);
                 if (slot < (unsigned int)kMaxSort) sorted[slot] = key;
             }
-        }
+        });
     }
     __syncthreads();
     for (int size = 2; size <= P; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (P >> 1); i += kSelThreads) {
+            for (int i = tid; i < (P >> 1); i += nthr) {
                 const int lo = ((i / stride) * stride * 2) + (i % stride);
                 const int hi = lo + stride;
                 const bool desc = ((lo & size) == 0);
@@ -394,7 +444,8 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
             __syncthreads();
         }
     }
-    for (int j = tid; j < k; j += kSelThreads) {
+    }
+    for (int j = tid; j < k; j += nthr) {
         const uint64_t key = j < (int)keff ? sorted[j] : 0;
         const uint32_t low = 0xFFFFFFFFu - (uint32_t)key;
         if (OUT == OUT_GROUPS) {
@@ -466,6 +517,8 @@ int launch_tile_rows(ivr_index *x, float *dst, const float *src, int64_t start, 
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
+
+int sel_threads(int64_t n) { return n <= 16 * 256 ? 256 : kSelThreads; }
 
 // choose the query tile width of the scan (queries per index pass = 16*QT)
 int pick_qt(int nq) { return nq <= 16 ? 1 : nq <= 32 ? 2 : nq <= 48 ? 3 : 4; }
@@ -678,7 +731,7 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         SrcGroupMax sg{x->gmax, mstride, ngroups};
         {
         IvrProf prof("select_groups", s, (double)nqc * ngroups * 4);
-        hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(kSelThreads), 0, s, sg, 0, ksel,
+        hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(sel_threads(ngroups)), 0, s, sg, 0, ksel,
                            (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr);
         }
         IVR_LAUNCH_CHECK();
@@ -692,7 +745,7 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         IVR_LAUNCH_CHECK();
         SrcKeys sk{x->cand, (int64_t)ksel * kGroupRows};
         IvrProf prof("select_final", s, (double)waves * kGroupRows * 8);
-        hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(kSelThreads), 0, s, sk, 0, k, id_base,
+        hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(sel_threads((int64_t)ksel * kGroupRows)), 0, s, sk, 0, k, id_base,
                            (uint32_t *)nullptr, D + (int64_t)q0 * k, I + (int64_t)q0 * k, (const int64_t *)nullptr);
         IVR_LAUNCH_CHECK();
     }
@@ -705,7 +758,7 @@ int ivr_topk_merge(ivr_ctx *ctx, const float *D_parts, const int64_t *I_parts, i
     IVR_REQUIRE(parts >= 1 && nq >= 1 && k >= 1 && k <= IVR_MAX_K, "ivr_topk_merge: parts=%d nq=%d k=%d", parts, nq, k);
     IVR_HIP(hipSetDevice(ctx->device));
     SrcParts sp{D_parts, I_parts, nq, k, (int64_t)parts * k};
-    hipLaunchKernelGGL((select_topk_kernel<SrcParts, OUT_DI_PARTS>), dim3(nq), dim3(kSelThreads), 0, (hipStream_t)stream, sp, 0,
+    hipLaunchKernelGGL((select_topk_kernel<SrcParts, OUT_DI_PARTS>), dim3(nq), dim3(sel_threads((int64_t)parts * k)), 0, (hipStream_t)stream, sp, 0,
                        k, (int64_t)0, (uint32_t *)nullptr, D, I, I_parts);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
