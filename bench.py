@@ -207,7 +207,7 @@ def main():
         pmc_ok = B == pmc.get("_frames_per_step", -1) and N == 1_000_000
 
         def traffic(*kernels):
-            if not pmc_ok or not all(k in pmc for k in kernels):
+            if not pmc_ok or not kernels or not all(k in pmc for k in kernels):
                 return None
             tot = sum(pmc[k]["hbm_bytes"] * pmc[k]["launches"] for k in kernels)
             return tot / sum(pmc[k]["launches"] for k in kernels)
@@ -237,9 +237,8 @@ def main():
                        "parallelism": f"{world} x (frames + index rows sharded per GPU); one all-gather of (score,id) + merge"},
             "pairs_per_s": N * world * Q / (search_ms * 1e-3), "search_ms_per_step": search_ms,
             "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TF,
-                         "traffic": traffic("gemm_kernel<bf16, 0, -1>", "gemm_kernel<bf16, 0, 0>", "gemm_kernel<bf16, 1, -1>",
-                                            "gemm_kernel<bf16, 2, -1>", "gemm_kernel<bf16, 3, -1>"),
-                         "kernel": "gemm_kernel<bf16> (all tower GEMM launches of the timed region)",
+                         "traffic": traffic(*[k for k in pmc if k.startswith(("gemm_big_kernel<bf16", "gemm_kernel<bf16"))]),
+                         "kernel": "gemm_big_kernel<bf16> / gemm_kernel<bf16> (all tower GEMM launches of the timed region)",
                          "avg_launch_ms": gemm_ms / max(1, gemm_launches), "launches": int(gemm_launches),
                          "flop_per_launch": gemm_flop / max(1, gemm_launches),
                          "by_call_site": {n: {"TFLOP/s": v["work"] / (v["ms"] * 1e-3) / 1e12, "ms": v["ms"] / v["launches"]}

@@ -549,25 +549,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// GEMM, ring version (production): 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), persistent workgroups (one per CU)
-// that walk a list of tiles, and ONE continuous LDS-DMA ring of 3 stages (48 KiB each: X 256 rows + W 128 rows of
-// 128 B) running two K steps ahead of the MFMAs - across tile boundaries too, so a tile's first stages land under
-// the previous tile's last K steps and epilogue.  Per K step: one counted wait (vmcnt(6) = the next stage's six
-// pieces of this wave may stay in flight; epilogue stores issued in between only make the wait stricter) + one
-// raw s_barrier, then the DMA for stage s+2 goes into the slot every wave finished reading before that barrier.
-// Tiles are dealt so that the 32 workgroups that share an XCD (blockIdx % 8) work on the same X row panels:
-// a panel is fetched into that XCD's L2 once and reused by all its column tiles.
-// ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int STAGES>
-struct RingCfg {
-    static constexpr int BM_ = 64 * WM, BN_ = 64 * WN, THREADS = 64 * WM * WN;
-    static constexpr int X_BYTES = BM_ * ROWB, W_BYTES = BN_ * ROWB, STAGE_BYTES = X_BYTES + W_BYTES;
-    static constexpr int LDS = STAGES * STAGE_BYTES;
-    static constexpr int XP = 8 / WN, WP = 8 / WM;          // 1 KiB pieces per wave per stage (X, W)
-    static constexpr int INFLIGHT = (XP + WP) * (STAGES - 2);   // pieces allowed outstanding at the top of a K step
-};
-
+// the i-th tile of a persistent workgroup (used by the experimental stream kernel below)
 struct TileWalk {      // the i-th tile of this workgroup
     int MT, NT, mode, x, j, J, G, b;
     __device__ void init(int M, int N, int bm, int bn) {
@@ -601,179 +583,6 @@ struct TileWalk {      // the i-th tile of this workgroup
         }
     }
 };
-
-template <typename T, int EPI, int ACT, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs g) {
-    using Cfg = RingCfg<WM, WN, STAGES>;
-    constexpr int RBM = Cfg::BM_, RBN = Cfg::BN_, RSTAGES = STAGES, RX_BYTES = Cfg::X_BYTES, RSTAGE_BYTES = Cfg::STAGE_BYTES;
-    constexpr int XP = Cfg::XP, WP = Cfg::WP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    constexpr int EPR = ROWB / (int)sizeof(T);
-    const int KT = g.K / EPR;
-    TileWalk tw;
-    tw.init(g.M, g.N, RBM, RBN);
-    const int ntiles = tw.count();
-    const int S = ntiles * KT;                       // stages this workgroup streams
-    if (S == 0) return;
-    const unsigned lds0 = (unsigned)(size_t)smem;
-
-    // ---- producer side: wave w issues X pieces XP*w .. and W pieces WP*w .. of every stage (1 KiB each)
-    const int prow = lane >> 3, pchunk = ((lane & 7) ^ (lane >> 3)) * 16;
-    const unsigned char *srcX[XP], *srcW[WP];
-    int p_tile = -1, p_kt = 0, p_slot = 0, p_item = 0;
-    auto issue = [&]() {
-        if (p_kt == 0) {                             // first stage of a tile: per-lane source rows of this tile
-            int tm, tn;
-            tw.get(p_item, tm, tn);
-#pragma unroll
-            for (int q = 0; q < XP; ++q) {
-                const int r = min(tm * RBM + 8 * (wave * XP + q) + prow, g.M - 1);
-                srcX[q] = reinterpret_cast<const unsigned char *>(g.A) + ((int64_t)r * g.lda) * sizeof(T) + pchunk;
-            }
-#pragma unroll
-            for (int q = 0; q < WP; ++q) {
-                const int r = min(tn * RBN + 8 * (wave * WP + q) + prow, g.N - 1);
-                srcW[q] = reinterpret_cast<const unsigned char *>(g.W) + ((int64_t)r * g.ldw) * sizeof(T) + pchunk;
-            }
-        }
-        unsigned char *base = smem + p_slot * RSTAGE_BYTES;
-        const int64_t adv = (int64_t)p_kt * ROWB;
-#pragma unroll
-        for (int q = 0; q < XP; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcX[q] + adv),
-                                             (__attribute__((address_space(3))) void *)(base + (wave * XP + q) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int q = 0; q < WP; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcW[q] + adv),
-                                             (__attribute__((address_space(3))) void *)(base + RX_BYTES + (wave * WP + q) * 1024), 16, 0,
-                                             0);
-        if (++p_kt == KT) {
-            p_kt = 0;
-            ++p_item;
-        }
-        p_slot = p_slot == RSTAGES - 1 ? 0 : p_slot + 1;
-    };
-    (void)p_tile;
-
-    // ---- consumer side
-    int foff[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) foff[kk] = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
-    f32x4 acc[4][4];   // [nt][mt]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int q = 0; q < STAGES - 1 && q < S; ++q) issue();
-    int c_kt = 0, c_slot = 0, c_item = 0;
-    for (int s = 0; s < S; ++s) {
-        // stage s has landed for this wave once at most the pieces of the STAGES-2 younger stages are outstanding; the
-        // barrier then makes that true for every wave and also orders every wave's reads of the slot refilled below
-        if (s + STAGES - 1 <= S)
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Cfg::INFLIGHT) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (s + STAGES - 1 < S) issue();
-        const unsigned lbase = lds0 + c_slot * RSTAGE_BYTES;
-        const unsigned xa = lbase + (wm * 64) * ROWB, wa = lbase + RX_BYTES + (wn * 64) * ROWB;
-        u32x4 xf[2][4], wf[2][4];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                asm volatile("ds_read_b128 %0, %1" : "=v"(xf[kk][t]) : "v"(xa + t * 16 * ROWB + foff[kk]));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(wf[kk][t]) : "v"(wa + t * 16 * ROWB + foff[kk]));
-            }
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(wf[0][nt], xf[0][mt], acc[nt][mt]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) mma_chunk<T>(wf[1][nt], xf[1][mt], acc[nt][mt]);
-        c_slot = c_slot == RSTAGES - 1 ? 0 : c_slot + 1;
-        if (++c_kt < KT) continue;
-
-        // ---- tile finished: epilogue (same register layout as gemm_kernel), then reset the accumulators
-        c_kt = 0;
-        int tm, tn;
-        tw.get(c_item++, tm, tn);
-        const int m0 = tm * RBM, n0 = tn * RBN;
-        int mrow[4], ncol[4];
-        bool mok[4], nok[4];
-        float4 bv[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            mrow[t] = m0 + wm * 64 + t * 16 + (lane & 15);
-            ncol[t] = n0 + wn * 64 + t * 16 + 4 * (lane >> 4);
-            mok[t] = mrow[t] < g.M;
-            nok[t] = ncol[t] < g.N;
-            mrow[t] = min(mrow[t], g.M - 1);
-            ncol[t] = min(ncol[t], g.N - 4);
-            bv[t] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + ncol[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (EPI == EPI_RESID || EPI == EPI_PATCH) {
-            float4 rv[4][4];
-            float *rowp[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if (EPI == EPI_RESID) {
-                    rowp[mt] = g.resid + (int64_t)mrow[mt] * g.ldr;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) rv[mt][nt] = *reinterpret_cast<const float4 *>(rowp[mt] + ncol[nt]);
-                } else {
-                    const int img = mrow[mt] / g.G2, pch = mrow[mt] % g.G2;
-                    rowp[mt] = g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        rv[mt][nt] = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol[nt]);
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    float4 r = rv[mt][nt];
-                    r.x += acc[nt][mt][0] + bv[nt].x;
-                    r.y += acc[nt][mt][1] + bv[nt].y;
-                    r.z += acc[nt][mt][2] + bv[nt].z;
-                    r.w += acc[nt][mt][3] + bv[nt].w;
-                    if (mok[mt] && nok[nt]) *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
-                }
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    float v[4] = {acc[nt][mt][0] + bv[nt].x, acc[nt][mt][1] + bv[nt].y, acc[nt][mt][2] + bv[nt].z,
-                                  acc[nt][mt][3] + bv[nt].w};
-                    if (ACT >= 0) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
-                    }
-                    if (mok[mt] && nok[nt]) {
-                        if (EPI == EPI_STORE)
-                            El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt], v);
-                        else
-                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt]) =
-                                make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                }
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // GEMM, stream version: one persistent 4-wave workgroup per CU (one wave per SIMD), 128 x 128 tile, and a
@@ -1263,14 +1072,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
 }
 
 // kernel choice, overridable for A/B runs (default: 4 for large problems, else 0): IVR_GEMM=0 128x128 kernel, 4 256x256
-// kernel, 1 persistent 128x128
-// (2 stages, 2 workgroups per CU), 2 persistent 256x128 (3 stages, 1 workgroup per CU), 3 stream kernel (4-stage ring,
-// counted waits, one 4-wave workgroup per CU)
+// kernel, 3 experimental stream kernel (persistent, 4-slot ring, counted waits, one 4-wave workgroup per CU)
 int ring_mode() {
     static int v = -2;
     if (v == -2) {
         const char *e = getenv("IVR_GEMM");
-        v = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : -1;
+        v = (e && (e[0] == '0' || e[0] == '3' || e[0] == '4')) ? e[0] - '0' : -1;
     }
     return v;
 }
@@ -1432,36 +1239,6 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
                 attr_done = true;
             }
             hipLaunchKernelGGL((gemm_stream_kernel<T, EPI, ACT, false>), dim3(grid), dim3(256), STREAM_LDS, s, g);
-        }
-        IVR_LAUNCH_CHECK();
-        return IVR_OK;
-    }
-    if (mode == 1 || mode == 2) {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (mode == 1) {            // 128 x 128, 4 waves, 2 stages, two persistent workgroups per CU
-            using Cfg = RingCfg<2, 2, 2>;
-            static bool attr_done = false;
-            if (!attr_done) {
-                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_kernel<T, EPI, ACT, 2, 2, 2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
-                attr_done = true;
-            }
-            const int MT = (g.M + Cfg::BM_ - 1) / Cfg::BM_, NT = (g.N + Cfg::BN_ - 1) / Cfg::BN_;
-            const int grid = std::min(MT * NT, 2 * cus);
-            hipLaunchKernelGGL((gemm_ring_kernel<T, EPI, ACT, 2, 2, 2>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS, s, g);
-        } else {                    // 256 x 128, 8 waves, 3 stages, one persistent workgroup per CU
-            using Cfg = RingCfg<4, 2, 3>;
-            static bool attr_done = false;
-            if (!attr_done) {
-                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_ring_kernel<T, EPI, ACT, 4, 2, 3>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
-                attr_done = true;
-            }
-            const int MT = (g.M + Cfg::BM_ - 1) / Cfg::BM_, NT = (g.N + Cfg::BN_ - 1) / Cfg::BN_;
-            const int grid = std::min(MT * NT, cus);
-            hipLaunchKernelGGL((gemm_ring_kernel<T, EPI, ACT, 4, 2, 3>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS, s, g);
         }
         IVR_LAUNCH_CHECK();
         return IVR_OK;

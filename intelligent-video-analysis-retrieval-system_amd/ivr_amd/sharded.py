@@ -91,12 +91,16 @@ class ShardedIndex:
         if self.world == 1:
             return D, I
         nq = D.shape[0]
-        Dg = torch.empty((self.world * nq, k), dtype=D.dtype, device=D.device)
-        Ig = torch.empty((self.world * nq, k), dtype=I.dtype, device=I.device)
-        # the single exchange step of the path: per-shard candidates to every rank
-        dist.all_gather_into_tensor(Dg, D.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(Ig, I.contiguous(), group=self.group)
-        Dg, Ig = Dg.view(self.world, nq, k), Ig.view(self.world, nq, k)
+        # the single exchange step of the path: ONE all-gather of nq*k*12 bytes per rank - (score f32, id i64) packed as
+        # three int32 words per candidate - so every rank holds every shard's candidates
+        cand = torch.empty((nq, k, 3), dtype=torch.int32, device=D.device)
+        cand[..., 0] = D.contiguous().view(torch.int32)
+        cand[..., 1:] = I.contiguous().view(torch.int32).view(nq, k, 2)
+        gathered = torch.empty((self.world * nq, k, 3), dtype=torch.int32, device=D.device)
+        dist.all_gather_into_tensor(gathered, cand, group=self.group)
+        gathered = gathered.view(self.world, nq, k, 3)
+        Dg = gathered[..., 0].contiguous().view(torch.float32)
+        Ig = gathered[..., 1:].contiguous().view(torch.int64).view(self.world, nq, k)
         if self.merge == "device" and Dg.is_cuda:
             from .index import topk_merge
             return topk_merge(Dg, Ig, k)
