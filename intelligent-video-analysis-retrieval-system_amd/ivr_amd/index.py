@@ -76,8 +76,19 @@ class FlatIPIndex:
     def train(self, x):  # core.py:817-820 calls train() when is_trained is False; flat indexes never need it
         return None
 
-    def add(self, x, normalize=False):
-        t = _dev_f32(x, self.device)
+    def add(self, x, normalize=False, chunk_rows=1 << 20):
+        """Append rows.  Host arrays are staged to HBM in chunks of `chunk_rows` so that a build of tens of millions of
+        rows never needs a second full copy on either side (the reference adds 10k-row slices, unified_index.py:1770)."""
+        if isinstance(x, np.ndarray) or (isinstance(x, torch.Tensor) and not x.is_cuda):
+            n = len(x)
+            if x.ndim != 2 or x.shape[1] != self.d:
+                raise ValueError(f"add expects [n,{self.d}], got {tuple(x.shape)}")
+            for i in range(0, n, chunk_rows):
+                self._add_device(_dev_f32(x[i:i + chunk_rows], self.device), normalize)
+            return
+        self._add_device(_dev_f32(x, self.device), normalize)
+
+    def _add_device(self, t, normalize):
         if t.dim() != 2 or t.shape[1] != self.d:
             raise ValueError(f"add expects [n,{self.d}], got {tuple(t.shape)}")
         with torch.cuda.device(self.device):

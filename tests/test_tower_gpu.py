@@ -132,3 +132,32 @@ def test_tower_errors():
     tw = Tower(cfg, w, max_batch=2)
     with pytest.raises(ValueError):
         tw.encode_patches(torch.zeros((3 * 49, 3072), dtype=torch.bfloat16, device="cuda"), 3)
+
+
+def test_config5_shape_mixed_text_and_image_queries():
+    """BASELINE config 5 at test scale (bf16 instead of fp8): ViT-L/14 image embeddings (768-d) as index rows, a mixed
+    batch of text-tower and image-tower queries, exact top-5 against the oracle on the same rows."""
+    from ivr_amd.index import FlatIPIndex
+    from ivr_amd.tower import Tower
+    from oracle import search_ref as S
+    vis, txt = C.CLIP_VIT_L14, C.CLIP_TEXT_L14
+    wv, wt = make_weights(vis, 13), make_weights(txt, 23)
+    frames = synth_frames(555, 6, 224, 224)
+    img = Tower(vis, wv, max_batch=6).encode_frames(frames)
+    rng = np.random.default_rng(4)
+    ids = np.full((3, 20), txt.eos_id, dtype=np.int64)
+    ids[:, 0] = txt.eos_id - 1
+    ids[:, 1:9] = rng.integers(1, 40000, (3, 8))
+    text = Tower(txt, wt, max_batch=4).encode_ids(ids)
+    assert img.shape == (6, 768) and text.shape == (3, 768)
+    ref_text = V.text_forward(txt, wt, ids)
+    assert _cos(text.cpu().numpy(), ref_text).min() > 1 - 1e-4
+    rows = S.normalize_rows_core(rng.standard_normal((5000, 768), dtype=np.float32)).astype(np.float32)
+    rows[:6] = img.cpu().numpy()
+    idx = FlatIPIndex(768)
+    idx.add(rows)
+    queries = torch.cat([text, img[:2]])                          # mixed text + image query batch, already on the device
+    D, I = idx.search_device(queries, 5)
+    Dr, Ir = S.flat_ip_search(rows, queries.cpu().numpy(), 5, dtype=np.float64)
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.abs(D.cpu().numpy() - Dr).max() < 1e-5
+    assert I[3, 0].item() == 0 and I[4, 0].item() == 1             # an image query finds its own row first
