@@ -361,6 +361,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // GEMM, large-tile version: 256 x 256 tile, 8 waves as 2(m) x 4(n), each wave 128 x 64 = 8 x 4 MFMA tiles.
 // Same staging scheme as gemm_kernel (two LDS buffers of 64 KiB filled by buffer_load ... lds, swizzled source, asm
@@ -549,6 +554,404 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// GEMM, large tile + deep ring: the 256 x 256 tile of gemm_big_kernel with the K step halved to 64 bytes per row so that
+// FOUR stages (32 KiB each) fit the 128 KiB of LDS and the LDS-DMA runs three stages (96 KiB) ahead instead of one.
+//   * LDS rows are 64 B; chunk c of row r sits at position c ^ ((r >> 1) & 3) (conflict-free for ds_read_b128, checked by
+//     enumeration of the four 16-lane groups); one DMA piece is 16 rows x 64 B, lane l -> row l >> 2, position l & 3.
+//   * software pipeline: the fragments of stage s+1 are read while the second half of stage s's MFMAs runs; the counted
+//     wait + barrier for stage s+1 therefore sits in the MIDDLE of step s, and the DMA for stage s+4 is issued right after
+//     it into the slot of stage s (every wave read its stage-s fragments before that barrier).
+//   * nothing else touches the vector-memory counter inside the K loop, so vmcnt(8) = "stages s+2, s+3 may stay in flight"
+//     is exact (4 pieces per wave per stage).
+// ---------------------------------------------------------------------------------------------
+constexpr int HROWB = 64, HX_BYTES = LBM * HROWB, HSTAGE = 2 * HX_BYTES, BIG32_LDS = 4 * HSTAGE;   // 128 KiB
+
+template <typename T, int EPI, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_big32_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
+    int tm, tn;
+    {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;
+        if (i >= lx * NT) return;
+        const int gm = g.group_m;
+        const int per = gm * NT, grp = i / per, within = i - grp * per;
+        const int gme = min(gm, lx - grp * gm);
+        tm = xcd + 8 * (grp * gm + within % gme);
+        tn = within / gme;
+    }
+    const int m0 = tm * LBM, n0 = tn * LBN;
+    constexpr int EPR = HROWB / (int)sizeof(T);          // elements of K per stage (32 bf16 / 16 f32)
+    const int KT = g.K / EPR;                            // host guarantees KT even and >= 4
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // 16 + 16 pieces of 1 KiB per stage (16 rows x 64 B each); wave w issues pieces 2w, 2w+1 of X and of W
+    unsigned voffX[2], voffW[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rr = lane >> 2, r = 16 * (wave * 2 + j) + rr, c = (lane & 3) ^ ((rr >> 1) & 3);
+        voffX[j] = (unsigned)(r * g.lda) * (unsigned)sizeof(T) + c * 16;
+        voffW[j] = (unsigned)(r * g.ldw) * (unsigned)sizeof(T) + c * 16;
+    }
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.A), 0, (int)((int64_t)g.M * g.lda * sizeof(T)), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * sizeof(T)), 0x00020000);
+    const unsigned sx0 = (unsigned)m0 * (unsigned)g.lda * (unsigned)sizeof(T), sw0 = (unsigned)n0 * (unsigned)g.ldw * (unsigned)sizeof(T);
+    auto stage = [&](int kt) {
+        unsigned char *base = smem + (kt & 3) * HSTAGE + (wave * 2) * 1024;
+        const unsigned adv = (unsigned)kt * HROWB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + j * 1024), 16, voffX[j],
+                                                     sx0 + adv, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + HX_BYTES + j * 1024), 16,
+                                                     voffW[j], sw0 + adv, 0, 0);
+        }
+    };
+    // fragment of a 16-row tile: row lane & 15, logical chunk lane >> 4 -> position (lane >> 4) ^ ((row >> 1) & 3)
+    const unsigned fo = (lane & 15) * HROWB + (((lane >> 4) ^ ((lane >> 1) & 3)) << 4);
+    const unsigned foX = lds0 + (wm * 128) * HROWB + fo, foW = lds0 + HX_BYTES + (wn * 64) * HROWB + fo;
+
+    f32x4 acc[4][8];   // [nt][mt]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define IVR_B32_READ(SLOT, XF, WF)                                                                         \
+    {                                                                                                      \
+        const unsigned xa = foX + (SLOT) * HSTAGE, wa = foW + (SLOT) * HSTAGE;                             \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(WF[0]) : "v"(wa));                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(WF[1]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(WF[2]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(WF[3]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(XF[0]) : "v"(xa));                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(XF[1]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(XF[2]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(XF[3]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(XF[4]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(XF[5]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(XF[6]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(XF[7]) : "v"(xa));                           \
+    }
+#define IVR_B32_MMA(XF, WF, LO)                                                                            \
+    _Pragma("unroll") for (int mt = LO; mt < LO + 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) \
+        mma_chunk<T>(WF[nt], XF[mt], acc[nt][mt]);
+#define IVR_B32_LGKM(N)                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);
+// one K step: first half of the MFMAs, counted wait + barrier for stage S+1, DMA for stage S+4, fragments of S+1, second half
+#define IVR_B32_STEP(S, CX, CW, NX, NW)                                                                    \
+    {                                                                                                      \
+        IVR_B32_MMA(CX, CW, 0)                                                                             \
+        if ((S) + 1 < KT) {                                                                                \
+            if ((S) + 3 < KT) wait_vm_barrier<8>();                                                        \
+            else if ((S) + 2 < KT) wait_vm_barrier<4>();                                                   \
+            else wait_vm_barrier<0>();                                                                     \
+            if ((S) + 4 < KT) stage((S) + 4);                                                              \
+            IVR_B32_READ(((S) + 1) & 3, NX, NW)                                                            \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        IVR_B32_MMA(CX, CW, 4)                                                                             \
+        IVR_B32_LGKM(0)                                                                                    \
+    }
+
+    u32x4 ax[8], aw[4], bx[8], bw[4];
+    stage(0);
+    stage(1);
+    stage(2);
+    stage(3);
+    wait_vm_barrier<12>();            // stage 0 landed (stages 1..3 = 12 pieces may stay in flight)
+    IVR_B32_READ(0, ax, aw)
+    IVR_B32_LGKM(0)
+    for (int kt = 0; kt < KT; kt += 2) {
+        IVR_B32_STEP(kt, ax, aw, bx, bw)
+        IVR_B32_STEP(kt + 1, bx, bw, ax, aw)
+    }
+#undef IVR_B32_READ
+#undef IVR_B32_MMA
+#undef IVR_B32_LGKM
+#undef IVR_B32_STEP
+
+    // epilogue in two halves of four row tiles (keeps the batched residual loads at 64 registers)
+    int ncol[4];
+    bool nok[4];
+    float4 bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ncol[t] = n0 + wn * 64 + t * 16 + 4 * (lane >> 4);
+        nok[t] = ncol[t] < g.N;
+        ncol[t] = min(ncol[t], g.N - 4);
+        bv[t] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + ncol[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int mrow[4];
+        bool mok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            mrow[t] = m0 + wm * 128 + (half * 4 + t) * 16 + (lane & 15);
+            mok[t] = mrow[t] < g.M;
+            mrow[t] = min(mrow[t], g.M - 1);
+        }
+        if (EPI == EPI_RESID || EPI == EPI_PATCH) {
+            float4 rv[4][4];
+            float *rowp[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (EPI == EPI_RESID) {
+                    rowp[mt] = g.resid + (int64_t)mrow[mt] * g.ldr;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) rv[mt][nt] = *reinterpret_cast<const float4 *>(rowp[mt] + ncol[nt]);
+                } else {
+                    const int img = mrow[mt] / g.G2, pch = mrow[mt] % g.G2;
+                    rowp[mt] = g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        rv[mt][nt] = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol[nt]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float4 r = rv[mt][nt];
+                    const f32x4 a = acc[nt][half * 4 + mt];
+                    r.x += a[0] + bv[nt].x;
+                    r.y += a[1] + bv[nt].y;
+                    r.z += a[2] + bv[nt].z;
+                    r.w += a[3] + bv[nt].w;
+                    if (mok[mt] && nok[nt]) *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f32x4 a = acc[nt][half * 4 + mt];
+                    float v[4] = {a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w};
+                    if (ACT >= 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
+                    }
+                    if (mok[mt] && nok[nt]) {
+                        if (EPI == EPI_STORE)
+                            El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt], v);
+                        else
+                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt]) =
+                                make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM, wide tile with two independent workgroups per CU: 256 x 128 tile, 4 waves as 2 x 2 with 128 x 64 per wave (the
+// big kernel's wave tile), K step of 64 bytes per row, THREE stages of 24 KiB = 72 KiB of LDS, so two workgroups share a
+// CU and their barrier phases decouple (one's fragment reads and waits sit under the other's MFMAs), while each keeps
+// two stages of LDS-DMA in flight.
+//   * LDS rows are 64 B; chunk c of row r sits at position c ^ ((r >> 1) & 3) (conflict-free for ds_read_b128, checked by
+//     enumeration of the four 16-lane groups); one DMA piece is 16 rows x 64 B, lane l -> row l >> 2, position l & 3.
+//   * software pipeline: the fragments of stage s+1 are read while the second half of stage s's MFMAs runs; the counted
+//     wait + barrier for stage s+1 therefore sits in the MIDDLE of step s, and the DMA for stage s+3 is issued right after
+//     it into the slot of stage s (every wave read its stage-s fragments before that barrier).
+//   * nothing else touches the vector-memory counter inside the K loop, so vmcnt(6) = "stage s+2 may stay in flight" is exact
+//     (6 pieces per wave per stage).
+// ---------------------------------------------------------------------------------------------
+constexpr int WBN = 128, WW_BYTES = WBN * HROWB, WSTAGE = HX_BYTES + WW_BYTES, WIDE_LDS = 3 * WSTAGE;   // 72 KiB
+
+template <typename T, int EPI, int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + WBN - 1) / WBN;
+    int tm, tn;
+    {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;
+        if (i >= lx * NT) return;
+        const int gm = g.group_m;
+        const int per = gm * NT, grp = i / per, within = i - grp * per;
+        const int gme = min(gm, lx - grp * gm);
+        tm = xcd + 8 * (grp * gm + within % gme);
+        tn = within / gme;
+    }
+    const int m0 = tm * LBM, n0 = tn * WBN;
+    constexpr int EPR = HROWB / (int)sizeof(T);          // elements of K per stage (32 bf16 / 16 f32)
+    const int KT = g.K / EPR;                            // host guarantees KT even and >= 4
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // 16 + 8 pieces of 1 KiB per stage (16 rows x 64 B each); wave w issues X pieces 4w..4w+3 and W pieces 2w, 2w+1
+    unsigned voffX[4], voffW[2];
+    {
+        const int rr = lane >> 2, c = (lane & 3) ^ ((rr >> 1) & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) voffX[j] = (unsigned)((16 * (wave * 4 + j) + rr) * g.lda) * (unsigned)sizeof(T) + c * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) voffW[j] = (unsigned)((16 * (wave * 2 + j) + rr) * g.ldw) * (unsigned)sizeof(T) + c * 16;
+    }
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.A), 0, (int)((int64_t)g.M * g.lda * sizeof(T)), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * sizeof(T)), 0x00020000);
+    const unsigned sx0 = (unsigned)m0 * (unsigned)g.lda * (unsigned)sizeof(T), sw0 = (unsigned)n0 * (unsigned)g.ldw * (unsigned)sizeof(T);
+    auto stage = [&](int kt, int slot) {
+        unsigned char *base = smem + slot * WSTAGE;
+        const unsigned adv = (unsigned)kt * HROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + (wave * 4 + j) * 1024), 16,
+                                                     voffX[j], sx0 + adv, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + HX_BYTES + (wave * 2 + j) * 1024),
+                                                     16, voffW[j], sw0 + adv, 0, 0);
+    };
+    // fragment of a 16-row tile: row lane & 15, logical chunk lane >> 4 -> position (lane >> 4) ^ ((row >> 1) & 3)
+    const unsigned fo = (lane & 15) * HROWB + (((lane >> 4) ^ ((lane >> 1) & 3)) << 4);
+    const unsigned foX = lds0 + (wm * 128) * HROWB + fo, foW = lds0 + HX_BYTES + (wn * 64) * HROWB + fo;
+
+    f32x4 acc[4][8];   // [nt][mt]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define IVR_B32_READ(SLOT, XF, WF)                                                                         \
+    {                                                                                                      \
+        const unsigned xa = foX + (SLOT) * WSTAGE, wa = foW + (SLOT) * WSTAGE;                             \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(WF[0]) : "v"(wa));                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(WF[1]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(WF[2]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(WF[3]) : "v"(wa));                           \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(XF[0]) : "v"(xa));                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(XF[1]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(XF[2]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(XF[3]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(XF[4]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(XF[5]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(XF[6]) : "v"(xa));                           \
+        asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(XF[7]) : "v"(xa));                           \
+    }
+#define IVR_B32_MMA(XF, WF, LO)                                                                            \
+    _Pragma("unroll") for (int mt = LO; mt < LO + 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) \
+        mma_chunk<T>(WF[nt], XF[mt], acc[nt][mt]);
+#define IVR_B32_LGKM(N)                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);
+// one K step: first half of the MFMAs, counted wait + barrier for stage S+1, DMA for stage S+3 into the slot of stage S,
+// fragments of S+1, second half.  sl = slot of stage S.
+#define IVR_B32_STEP(S, CX, CW, NX, NW)                                                                    \
+    {                                                                                                      \
+        IVR_B32_MMA(CX, CW, 0)                                                                             \
+        const int nsl = sl == 2 ? 0 : sl + 1;                                                              \
+        if ((S) + 1 < KT) {                                                                                \
+            if ((S) + 2 < KT) wait_vm_barrier<6>();                                                        \
+            else wait_vm_barrier<0>();                                                                     \
+            if ((S) + 3 < KT) stage((S) + 3, sl);                                                          \
+            IVR_B32_READ(nsl, NX, NW)                                                                      \
+        }                                                                                                  \
+        sl = nsl;                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        IVR_B32_MMA(CX, CW, 4)                                                                             \
+        IVR_B32_LGKM(0)                                                                                    \
+    }
+
+    u32x4 ax[8], aw[4], bx[8], bw[4];
+    stage(0, 0);
+    stage(1, 1);
+    stage(2, 2);
+    wait_vm_barrier<12>();            // stage 0 landed (stages 1, 2 = 12 pieces may stay in flight)
+    int sl = 0;
+    IVR_B32_READ(0, ax, aw)
+    IVR_B32_LGKM(0)
+    for (int kt = 0; kt < KT; kt += 2) {
+        IVR_B32_STEP(kt, ax, aw, bx, bw)
+        IVR_B32_STEP(kt + 1, bx, bw, ax, aw)
+    }
+#undef IVR_B32_READ
+#undef IVR_B32_MMA
+#undef IVR_B32_LGKM
+#undef IVR_B32_STEP
+
+    // epilogue in two halves of four row tiles (keeps the batched residual loads at 64 registers)
+    int ncol[4];
+    bool nok[4];
+    float4 bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ncol[t] = n0 + wn * 64 + t * 16 + 4 * (lane >> 4);
+        nok[t] = ncol[t] < g.N;
+        ncol[t] = min(ncol[t], g.N - 4);
+        bv[t] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + ncol[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int mrow[4];
+        bool mok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            mrow[t] = m0 + wm * 128 + (half * 4 + t) * 16 + (lane & 15);
+            mok[t] = mrow[t] < g.M;
+            mrow[t] = min(mrow[t], g.M - 1);
+        }
+        if (EPI == EPI_RESID || EPI == EPI_PATCH) {
+            float4 rv[4][4];
+            float *rowp[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (EPI == EPI_RESID) {
+                    rowp[mt] = g.resid + (int64_t)mrow[mt] * g.ldr;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) rv[mt][nt] = *reinterpret_cast<const float4 *>(rowp[mt] + ncol[nt]);
+                } else {
+                    const int img = mrow[mt] / g.G2, pch = mrow[mt] % g.G2;
+                    rowp[mt] = g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        rv[mt][nt] = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol[nt]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float4 r = rv[mt][nt];
+                    const f32x4 a = acc[nt][half * 4 + mt];
+                    r.x += a[0] + bv[nt].x;
+                    r.y += a[1] + bv[nt].y;
+                    r.z += a[2] + bv[nt].z;
+                    r.w += a[3] + bv[nt].w;
+                    if (mok[mt] && nok[nt]) *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f32x4 a = acc[nt][half * 4 + mt];
+                    float v[4] = {a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w};
+                    if (ACT >= 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
+                    }
+                    if (mok[mt] && nok[nt]) {
+                        if (EPI == EPI_STORE)
+                            El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt], v);
+                        else
+                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt]) =
+                                make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+        }
+    }
+}
+
 // the i-th tile of a persistent workgroup (used by the experimental stream kernel below)
 struct TileWalk {      // the i-th tile of this workgroup
     int MT, NT, mode, x, j, J, G, b;
@@ -599,10 +1002,6 @@ struct TileWalk {      // the i-th tile of this workgroup
 // ---------------------------------------------------------------------------------------------
 constexpr int SSTAGES = 4, STILE = 2 * TILE_BYTES, STREAM_LDS = SSTAGES * STILE;   // 128 KiB
 
-template <int N>
-__device__ __forceinline__ void wait_vm_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
 
 template <typename T, int EPI, int ACT, bool HASBIAS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_stream_kernel(GemmArgs g) {
@@ -1077,7 +1476,7 @@ int ring_mode() {
     static int v = -2;
     if (v == -2) {
         const char *e = getenv("IVR_GEMM");
-        v = (e && (e[0] == '0' || e[0] == '3' || e[0] == '4')) ? e[0] - '0' : -1;
+        v = (e && (e[0] == '0' || (e[0] >= '3' && e[0] <= '6'))) ? e[0] - '0' : -1;
     }
     return v;
 }
@@ -1193,6 +1592,48 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     int mode = ring_mode();
     // default (-1): the 256 x 256 kernel once it fills the chip, the 128 x 128 kernel for small problems
     if (mode < 0) mode = ((g.M + LBM - 1) / LBM) * ((g.N + LBN - 1) / LBN) >= 192 ? 4 : 0;
+    if (mode == 6 && (g.K / (HROWB / (int)sizeof(T))) >= 4 && (g.K / (HROWB / (int)sizeof(T))) % 2 == 0) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_wide_kernel<T, EPI, ACT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
+            attr_done = true;
+        }
+        GemmArgs ga = g;
+        static int group_m = -1;
+        if (group_m < 0) {
+            const char *e = getenv("IVR_GEMM_GROUP_M");
+            group_m = e ? std::max(1, atoi(e)) : 0;
+        }
+        const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + WBN - 1) / WBN;
+        ga.group_m = group_m ? group_m : (NT <= 6 ? 2 : 8);
+        const int grid = 8 * ((MT + 7) / 8) * NT;
+        hipLaunchKernelGGL((gemm_wide_kernel<T, EPI, ACT>), dim3(grid), dim3(256), WIDE_LDS, s, ga);
+        IVR_LAUNCH_CHECK();
+        return IVR_OK;
+    }
+    if (mode == 6) mode = 4;
+    if (mode == 5 && (g.K / (HROWB / (int)sizeof(T))) >= 4 && (g.K / (HROWB / (int)sizeof(T))) % 2 == 0) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big32_kernel<T, EPI, ACT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, BIG32_LDS));
+            attr_done = true;
+        }
+        GemmArgs ga = g;
+        static int group_m = -1;
+        if (group_m < 0) {
+            const char *e = getenv("IVR_GEMM_GROUP_M");
+            group_m = e ? std::max(1, atoi(e)) : 0;
+        }
+        const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
+        ga.group_m = group_m ? group_m : (NT <= 3 ? 2 : 8);
+        const int grid = 8 * ((MT + 7) / 8) * NT;
+        hipLaunchKernelGGL((gemm_big32_kernel<T, EPI, ACT>), dim3(grid), dim3(512), BIG32_LDS, s, ga);
+        IVR_LAUNCH_CHECK();
+        return IVR_OK;
+    }
+    if (mode == 5) mode = 4;
     if (mode == 4) {
         static bool attr_done = false;
         if (!attr_done) {
