@@ -361,6 +361,97 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// Wide epilogue of the 128 x 64 wave block (8 x 4 MFMA tiles): the block goes through 16 KiB of the (by then idle) LDS
+// owned by the wave, so that every global store / residual load covers whole rows of the block (bf16: 8 rows x 128 B per
+// instruction, f32 residual: 4 rows x 256 B) instead of 16 rows x 32 or 64 B straight from the MFMA layout.  The bf16
+// store tail is bound by the number of vector-memory instructions and the lines each one touches, not by bytes (s_memtime
+// stamps: 18.9k -> 6.3k cycles of a 55k-cycle qkv tile).  LDS images are XOR-swizzled by row: writes and reads are
+// conflict-free.
+template <typename T, int EPI, int ACT>
+__device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4][8], unsigned char *wb, int row0, int col0, int lane) {
+    const int r = lane & 15, gq = lane >> 4;
+    float4 bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+        bv[nt] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + col0 + nt * 16 + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_STORE) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 a = acc[nt][mt];
+                float v[4] = {a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w};
+                if (ACT >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = act_fn<true>(v[i], ACT);
+                }
+                uint2 o;
+                o.x = ivr_pack_bf16x2(v[0], v[1]);
+                o.y = ivr_pack_bf16x2(v[2], v[3]);
+                const int chunk = (nt * 2 + (gq >> 1)) ^ (r & 7);
+                *reinterpret_cast<uint2 *>(wb + (mt * 16 + r) * 128 + chunk * 16 + (gq & 1) * 8) = o;
+            }
+        unsigned short *outp = reinterpret_cast<unsigned short *>(g.out) + col0 + (lane & 7) * 8;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int R = it * 8 + (lane >> 3);
+            const uint4 v = *reinterpret_cast<const uint4 *>(wb + R * 128 + (((lane & 7) ^ (R & 7)) << 4));
+            if (row0 + R < g.M) *reinterpret_cast<uint4 *>(outp + (int64_t)(row0 + R) * g.ldo) = v;
+        }
+    } else {
+        float *resp = g.resid + col0 + (lane & 15) * 4;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 rv[8];                                 // residual rows in two batches of 8 (register budget)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int grow = min(row0 + half * 64 + it * 4 + (lane >> 4), g.M - 1);
+                rv[it] = *reinterpret_cast<const float4 *>(resp + (int64_t)grow * g.ldr);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f32x4 a = acc[nt][half * 4 + mt];
+                    const int chunk = (nt * 4 + gq) ^ r;
+                    *reinterpret_cast<float4 *>(wb + (mt * 16 + r) * 256 + chunk * 16) =
+                        make_float4(a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w);
+                }
+#pragma unroll
+            for (int b8 = 0; b8 < 2; ++b8) {
+                if (b8 == 1) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int grow = min(row0 + half * 64 + (8 + it) * 4 + (lane >> 4), g.M - 1);
+                        rv[it] = *reinterpret_cast<const float4 *>(resp + (int64_t)grow * g.ldr);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int R = (b8 * 8 + it) * 4 + (lane >> 4), grow = row0 + half * 64 + R;
+                    const float4 v = *reinterpret_cast<const float4 *>(wb + R * 256 + (((lane & 15) ^ (R & 15)) << 4));
+                    if (grow < g.M)
+                        *reinterpret_cast<float4 *>(resp + (int64_t)grow * g.ldr) =
+                            make_float4(rv[it].x + v.x, rv[it].y + v.y, rv[it].z + v.z, rv[it].w + v.w);
+                }
+            }
+        }
+    }
+}
+
+#ifdef IVR_GEMM_STAMPS
+// diagnostic build only: per-workgroup s_memtime stamps (entry, first stage landed, K loop done, stores drained)
+__device__ unsigned long long ivr_gemm_stamps[16384][6];   // [4], [5]: s_memrealtime (100 MHz) at stamps 0 and 3
+#define IVR_STAMP(I)                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                          \
+        ivr_gemm_stamps[blockIdx.x][I] = __builtin_amdgcn_s_memtime();                                     \
+        if ((I) == 0) ivr_gemm_stamps[blockIdx.x][4] = __builtin_amdgcn_s_memrealtime();                   \
+        if ((I) == 3) ivr_gemm_stamps[blockIdx.x][5] = __builtin_amdgcn_s_memrealtime();                   \
+    }
+#else
+#define IVR_STAMP(I)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -376,9 +467,15 @@ __device__ __forceinline__ void wait_vm_barrier() {
 constexpr int LBM = 256, LBN = 256, LX_BYTES = LBM * ROWB, LW_BYTES = LBN * ROWB, LSTAGE = LX_BYTES + LW_BYTES;
 constexpr int BIG_LDS = 2 * LSTAGE;   // 128 KiB
 
-template <typename T, int EPI, int ACT>
+template <typename T, int EPI, int ACT, int PIPE>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // de-phase the CUs: with one workgroup per CU and equal tiles every CU would compute, then store, in step, and the
+    // store / residual traffic of the whole chip would hit HBM in bursts while the MFMAs idle.  The first wave of
+    // workgroups starts with a delay of (0..7) x stagger x 8k cycles, later ones inherit the offset.
+    if (g.stagger && blockIdx.x < 256)
+        for (int i = ((blockIdx.x >> 3) & 7) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
+    IVR_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -458,13 +555,123 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
     __builtin_amdgcn_sched_barrier(0);
 
+    u32x4 xa0[8], wa0[4], xa1[8], wa1[4];
+    if (PIPE == 2) {
+        // as PIPE == 1, and the LDS-DMA pieces and fragment reads are spread between groups of four MFMAs instead of being
+        // issued back to back after the barrier: the vector-memory path takes one 1 KiB piece per ~16 cycles per CU, so 64
+        // pieces issued at once by the 8 waves hold every wave's issue for ~1000 cycles with no MFMA behind them.
+        auto piece = [&](int kt, int buf, int j) {
+            unsigned char *base = smem + buf * LSTAGE + (wave * 4) * 1024;
+            const unsigned adv = (unsigned)kt * ROWB;
+            if (j < 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + j * 1024), 16, voffX[j],
+                                                         sx0 + adv, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + LX_BYTES + (j - 4) * 1024),
+                                                         16, voffW[j - 4], sw0 + adv, 0, 0);
+        };
+#define IVR_ROW(XF, WF, MT)                                                                                \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) mma_chunk<T>(WF[nt], XF[MT], acc[nt][MT]);            \
+    __builtin_amdgcn_sched_barrier(0);
+#define IVR_RD4(DST, ADDR, O0)                                                                             \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[0]) : "v"(ADDR), "n"(O0));                      \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[1]) : "v"(ADDR), "n"(O0 + 2048));               \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[2]) : "v"(ADDR), "n"(O0 + 4096));               \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[3]) : "v"(ADDR), "n"(O0 + 6144));
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        IVR_STAMP(1)
+        if (KT > 1) stage(1, 1);
+        {
+            const unsigned wa = foW[0], xa = foX[0];
+            u32x4 *xlo = xa0, *xhi = xa0 + 4;
+            IVR_RD4(wa0, wa, 0)
+            IVR_RD4(xlo, xa, 0)
+            IVR_RD4(xhi, xa, 8192)
+        }
+        for (int kt = 0; kt < KT; ++kt) {
+            const unsigned boff = (kt & 1) * LSTAGE, noff = ((kt + 1) & 1) * LSTAGE;
+            const bool tail = kt >= 1 && kt + 1 < KT;       // last two pieces of stage kt+1 (the first stage-1 DMA is whole)
+            const bool more = kt + 2 < KT, next = kt + 1 < KT;
+            u32x4 *x1lo = xa1, *x1hi = xa1 + 4, *x0lo = xa0, *x0hi = xa0 + 4;
+            const unsigned wa = foW[1] + boff, xa = foX[1] + boff;
+            IVR_BIG_WAIT(4)                 // W + first four X fragments of set 0
+            IVR_ROW(xa0, wa0, 0)
+            if (tail) piece(kt + 1, (kt + 1) & 1, 6);
+            IVR_ROW(xa0, wa0, 1)
+            IVR_RD4(wa1, wa, 0)
+            IVR_ROW(xa0, wa0, 2)
+            if (tail) piece(kt + 1, (kt + 1) & 1, 7);
+            IVR_ROW(xa0, wa0, 3)
+            IVR_RD4(x1lo, xa, 0)
+            IVR_BIG_WAIT(8)                 // all of set 0
+            IVR_ROW(xa0, wa0, 4)
+            IVR_ROW(xa0, wa0, 5)
+            IVR_RD4(x1hi, xa, 8192)
+            IVR_ROW(xa0, wa0, 6)
+            IVR_ROW(xa0, wa0, 7)
+            IVR_BIG_WAIT(0)                 // this wave has read everything it needs from the stage's buffer
+            const unsigned nwa = foW[0] + noff, nxa = foX[0] + noff;
+            if (next) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            IVR_ROW(xa1, wa1, 0)
+            if (more) piece(kt + 2, kt & 1, 0);
+            IVR_ROW(xa1, wa1, 1)
+            if (next) { IVR_RD4(wa0, nwa, 0) }
+            if (more) piece(kt + 2, kt & 1, 4);
+            IVR_ROW(xa1, wa1, 2)
+            if (more) piece(kt + 2, kt & 1, 1);
+            IVR_ROW(xa1, wa1, 3)
+            if (next) { IVR_RD4(x0lo, nxa, 0) }
+            if (more) piece(kt + 2, kt & 1, 5);
+            IVR_ROW(xa1, wa1, 4)
+            if (more) piece(kt + 2, kt & 1, 2);
+            IVR_ROW(xa1, wa1, 5)
+            if (next) { IVR_RD4(x0hi, nxa, 8192) }
+            IVR_ROW(xa1, wa1, 6)
+            if (more) piece(kt + 2, kt & 1, 3);
+            IVR_ROW(xa1, wa1, 7)
+        }
+        IVR_BIG_WAIT(0)
+        IVR_STAMP(2)
+#undef IVR_ROW
+#undef IVR_RD4
+    } else if (PIPE == 1) {
+        // software pipeline across the barrier: set 0 of stage kt+1 is read under the second half of stage kt's MFMAs, so
+        // no MFMA ever waits for a fragment read that was issued after a barrier.  The counted wait + barrier sits in the
+        // MIDDLE of the stage (all waves have then read both sets of stage kt, so its buffer can take the DMA of stage kt+2).
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (KT > 1) stage(1, 1);
+        {
+            const unsigned boff = 0;
+            IVR_BIG_READ(0, xa0, wa0)
+        }
+        for (int kt = 0; kt < KT; ++kt) {
+            const unsigned boff = (kt & 1) * LSTAGE;
+            IVR_BIG_WAIT(4)                 // W + first four X fragments of set 0
+            IVR_BIG_MMA(xa0, wa0, 0)
+            IVR_BIG_READ(1, xa1, wa1)
+            IVR_BIG_WAIT(12)                // all of set 0 (set 1 still in flight)
+            IVR_BIG_MMA(xa0, wa0, 4)
+            IVR_BIG_WAIT(0)                 // this wave has read everything it needs from the stage's buffer
+            if (kt + 1 < KT) {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (kt + 2 < KT) stage(kt + 2, kt & 1);
+                const unsigned boff = ((kt + 1) & 1) * LSTAGE;
+                IVR_BIG_READ(0, xa0, wa0)
+            }
+            IVR_BIG_MMA(xa1, wa1, 0)
+            IVR_BIG_MMA(xa1, wa1, 4)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        IVR_BIG_WAIT(0)
+    } else {
     stage(0, 0);
     for (int kt = 0; kt < KT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
         const unsigned boff = (kt & 1) * LSTAGE;
         // two fragment sets: the 12 reads of the second half-step are issued under the first half-step's MFMAs
-        u32x4 xa0[8], wa0[4], xa1[8], wa1[4];
         IVR_BIG_READ(0, xa0, wa0)
         IVR_BIG_WAIT(4)                 // W + first four X fragments of set 0
         IVR_BIG_MMA(xa0, wa0, 0)
@@ -476,11 +683,25 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
         IVR_BIG_WAIT(0)
         IVR_BIG_MMA(xa1, wa1, 4)
         __builtin_amdgcn_sched_barrier(0);
+#ifdef IVR_GEMM_STAMPS
+        if (kt == 0) { IVR_STAMP(1) }
+#endif
+    }
+    IVR_STAMP(2)
     }
 #undef IVR_BIG_MMA
 #undef IVR_BIG_WAIT
 #undef IVR_BIG_READ
 
+    if (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_RESID) && g.wide_epi) {
+        __builtin_amdgcn_s_barrier();                         // every wave has read its last fragments
+        wide_epilogue<T, EPI, ACT>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
+#ifdef IVR_GEMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IVR_STAMP(3)
+#endif
+        return;
+    }
     // epilogue in two halves of four row tiles (keeps the batched residual loads at 64 registers)
     int ncol[4];
     bool nok[4];
@@ -552,6 +773,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
                 }
         }
     }
+#ifdef IVR_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IVR_STAMP(3)
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -879,6 +1104,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmArgs g) {
 #undef IVR_B32_LGKM
 #undef IVR_B32_STEP
 
+    if (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_RESID) && g.wide_epi) {
+        __builtin_amdgcn_s_barrier();                         // every wave has read its last fragments
+        wide_epilogue<T, EPI, ACT>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
+        return;
+    }
     // epilogue in two halves of four row tiles (keeps the batched residual loads at 64 registers)
     int ncol[4];
     bool nok[4];
@@ -1476,7 +1706,7 @@ int ring_mode() {
     static int v = -2;
     if (v == -2) {
         const char *e = getenv("IVR_GEMM");
-        v = (e && (e[0] == '0' || (e[0] >= '3' && e[0] <= '6'))) ? e[0] - '0' : -1;
+        v = (e && (e[0] == '0' || (e[0] >= '3' && e[0] <= '8'))) ? e[0] - '0' : -1;
     }
     return v;
 }
@@ -1607,6 +1837,15 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
         }
         const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + WBN - 1) / WBN;
         ga.group_m = group_m ? group_m : (NT <= 6 ? 2 : 8);
+        {
+            const char *e = getenv("IVR_GEMM_WIDE_EPI");
+            const bool wide = e ? atoi(e) != 0 : true;
+            const bool bias_ok = !g.bias || reinterpret_cast<uintptr_t>(g.bias) % 16 == 0;
+            if (EPI == EPI_STORE)
+                ga.wide_epi = wide && bias_ok && g.N % WBN == 0 && g.ldo % 8 == 0 && reinterpret_cast<uintptr_t>(g.out) % 16 == 0;
+            else if (EPI == EPI_RESID)
+                ga.wide_epi = wide && bias_ok && g.N % WBN == 0 && g.ldr % 4 == 0 && reinterpret_cast<uintptr_t>(g.resid) % 16 == 0;
+        }
         const int grid = 8 * ((MT + 7) / 8) * NT;
         hipLaunchKernelGGL((gemm_wide_kernel<T, EPI, ACT>), dim3(grid), dim3(256), WIDE_LDS, s, ga);
         IVR_LAUNCH_CHECK();
@@ -1634,13 +1873,7 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
         return IVR_OK;
     }
     if (mode == 5) mode = 4;
-    if (mode == 4) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS));
-            attr_done = true;
-        }
+    if (mode == 4 || mode == 7 || mode == 8) {
         GemmArgs ga = g;
         static int group_m = -1;
         if (group_m < 0) {
@@ -1649,8 +1882,48 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
         }
         const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
         ga.group_m = group_m ? group_m : (NT <= 3 ? 2 : 8);     // measured: narrow outputs want short groups
+        static int stagger = -1;
+        if (stagger < 0) {
+            const char *e = getenv("IVR_GEMM_STAGGER");
+            stagger = e ? atoi(e) : 0;
+        }
+        ga.stagger = stagger;
+        static int wide = -1;
+        if (wide < 0) {
+            const char *e = getenv("IVR_GEMM_WIDE_EPI");
+            wide = e ? atoi(e) : 1;
+        }
+        if (EPI == EPI_STORE)
+            ga.wide_epi = wide && g.N % LBN == 0 && g.ldo % 8 == 0 && reinterpret_cast<uintptr_t>(g.out) % 16 == 0;
+        else if (EPI == EPI_RESID)
+            ga.wide_epi = wide && g.N % LBN == 0 && g.ldr % 4 == 0 && reinterpret_cast<uintptr_t>(g.resid) % 16 == 0;
+        if (ga.wide_epi && g.bias && reinterpret_cast<uintptr_t>(g.bias) % 16 != 0) ga.wide_epi = 0;
         const int grid = 8 * ((MT + 7) / 8) * NT;
-        hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT>), dim3(grid), dim3(512), BIG_LDS, s, ga);
+        if (mode == 8) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT, 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT, 2>), dim3(grid), dim3(512), BIG_LDS, s, ga);
+        } else if (mode == 7) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT, 1>), dim3(grid), dim3(512), BIG_LDS, s, ga);
+        } else {
+            static bool attr_done = false;
+            if (!attr_done) {
+                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT, 0>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT, 0>), dim3(grid), dim3(512), BIG_LDS, s, ga);
+        }
         IVR_LAUNCH_CHECK();
         return IVR_OK;
     }
@@ -1800,3 +2073,9 @@ int ivr_launch_f_normalize(const float *x, float *out, int n, int d, int normali
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
+
+#ifdef IVR_GEMM_STAMPS
+extern "C" int ivr_debug_gemm_stamps(unsigned long long *host_out, int nblocks) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ivr_gemm_stamps), sizeof(unsigned long long) * 6 * nblocks) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -17,6 +17,9 @@ shapes = [("qkv", M, 2304, 768, EPI_STORE, -1), ("attn_out", M, 768, 768, EPI_RE
 for name, m, n, k, epi, act in shapes:
     x = (torch.randn((m, k), device="cuda") * 0.5).to(torch.bfloat16)
     w = (torch.randn((n, k), device="cuda") * 0.05).to(torch.bfloat16)
+    if os.environ.get("IVR_BENCH_ZERO"):       # DVFS probe: all-zero operands draw less power, so the clock stays up
+        x.zero_()
+        w.zero_()
     b = torch.randn(n, device="cuda")
     r = torch.zeros((m, n), device="cuda") if epi == EPI_RESID else None
     for _ in range(3):
@@ -29,4 +32,18 @@ for name, m, n, k, epi, act in shapes:
     torch.cuda.synchronize()
     _ffi.profile_enable(False)
     p = _ffi.profile_read()["linear"]
-    print(f"{name:9s} M={m:7d} N={n:5d} K={k:5d}  {p['ms'] / p['launches']:8.3f} ms  {p['work'] / (p['ms'] * 1e-3) / 1e12:8.1f} TFLOP/s")
+    line = f"{name:9s} M={m:7d} N={n:5d} K={k:5d}  {p['ms'] / p['launches']:8.3f} ms  {p['work'] / (p['ms'] * 1e-3) / 1e12:8.1f} TFLOP/s"
+    if os.environ.get("IVR_BENCH_VENDOR"):
+        # the vendor library (hipBLASLt through torch) on the bare product, no bias / activation / residual: a practical ceiling
+        wt = w.t()
+        for _ in range(3):
+            torch.matmul(x, wt)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            torch.matmul(x, wt)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        line += f"   | hipBLASLt bare matmul {ms:8.3f} ms {2.0 * m * n * k / (ms * 1e-3) / 1e12:8.1f} TFLOP/s"
+    print(line)
