@@ -20,7 +20,6 @@ struct GemmArgs {
     int act = -1;                  // EPI_STORE: -1 none, else IVR_ACT_*
     const char *tag = nullptr;     // profiler name of this call site
     int group_m = 8;               // row panels per L2-resident group (tile order of gemm_kernel)
-    int stagger = 0;               // 256 x 256 kernel: start delay step of the first wave of workgroups (x 8k cycles)
     int wide_epi = 0;              // set by the launcher: 256 x 256 kernel may use the row-wide LDS-staged epilogue
 };
 

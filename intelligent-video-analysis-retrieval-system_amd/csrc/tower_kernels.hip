@@ -460,21 +460,25 @@ __device__ __forceinline__ void wait_vm_barrier() {
 // ---------------------------------------------------------------------------------------------
 // GEMM, large-tile version: 256 x 256 tile, 8 waves as 2(m) x 4(n), each wave 128 x 64 = 8 x 4 MFMA tiles.
 // Same staging scheme as gemm_kernel (two LDS buffers of 64 KiB filled by buffer_load ... lds, swizzled source, asm
-// fragment reads), but half the operand bytes per FLOP (what the DMA has to keep in flight to cover its latency), 0.375
-// instead of 0.5 fragment reads per MFMA, and a quarter of the tile prologues / epilogues per FLOP.  One workgroup per
-// CU (128 KiB of LDS), two waves per SIMD.
+// fragment reads), but half the operand bytes per FLOP, 0.375 instead of 0.5 fragment reads per MFMA, and a quarter of
+// the tile prologues / epilogues per FLOP.  One workgroup per CU (128 KiB of LDS), two waves per SIMD.
+//   * software pipeline across the barrier: per stage a wave holds two fragment sets (the two 32-wide K halves).  Set 1
+//     of stage kt is read under the MFMAs of set 0, and set 0 of stage kt+1 under the MFMAs of set 1, so no MFMA waits
+//     for a read issued after a barrier.  The single wait + barrier of a stage sits in its MIDDLE: by then every wave
+//     has read both sets of stage kt, so that buffer can take the DMA of stage kt+2, and stage kt+1 (issued one stage
+//     earlier) has landed.
+//   * the 8 DMA pieces and 12 fragment reads a wave issues per stage are spread between groups of four MFMAs instead of
+//     being issued back to back behind the barrier (64 pieces at once from the 8 waves hold every wave's issue with no
+//     MFMA queued behind them).  The last two pieces of a stage go out early in the following stage.
+//   * s_memtime stamps (-DIVR_GEMM_STAMPS, tools/gemm_stamps.py) on a K=768 qkv tile: prologue 2.5k, K loop 30.8k
+//     (2566 cycles per stage, 2048 = MFMA-bound), epilogue 6.7k cycles.
 // ---------------------------------------------------------------------------------------------
 constexpr int LBM = 256, LBN = 256, LX_BYTES = LBM * ROWB, LW_BYTES = LBN * ROWB, LSTAGE = LX_BYTES + LW_BYTES;
 constexpr int BIG_LDS = 2 * LSTAGE;   // 128 KiB
 
-template <typename T, int EPI, int ACT, int PIPE>
+template <typename T, int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // de-phase the CUs: with one workgroup per CU and equal tiles every CU would compute, then store, in step, and the
-    // store / residual traffic of the whole chip would hit HBM in bursts while the MFMAs idle.  The first wave of
-    // workgroups starts with a delay of (0..7) x stagger x 8k cycles, later ones inherit the offset.
-    if (g.stagger && blockIdx.x < 256)
-        for (int i = ((blockIdx.x >> 3) & 7) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
     IVR_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -532,44 +536,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#define IVR_BIG_READ(KK, XF, WF)                                                                           \
-    {                                                                                                      \
-        const unsigned xa = foX[KK] + boff, wa = foW[KK] + boff;                                           \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(WF[0]) : "v"(wa));                                       \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(WF[1]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(WF[2]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(WF[3]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(XF[0]) : "v"(xa));                                       \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(XF[1]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(XF[2]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(XF[3]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(XF[4]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(XF[5]) : "v"(xa));                          \
-        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(XF[6]) : "v"(xa));                          \
-        asm volatile("ds_read_b128 %0, %1 offset:14336" : "=v"(XF[7]) : "v"(xa));                          \
-    }
-#define IVR_BIG_MMA(XF, WF, LO)                                                                            \
-    _Pragma("unroll") for (int mt = LO; mt < LO + 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) \
-        mma_chunk<T>(WF[nt], XF[mt], acc[nt][mt]);
-#define IVR_BIG_WAIT(N)                                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
-    __builtin_amdgcn_sched_barrier(0);
-
-    u32x4 xa0[8], wa0[4], xa1[8], wa1[4];
-    if (PIPE == 2) {
-        // as PIPE == 1, and the LDS-DMA pieces and fragment reads are spread between groups of four MFMAs instead of being
-        // issued back to back after the barrier: the vector-memory path takes one 1 KiB piece per ~16 cycles per CU, so 64
-        // pieces issued at once by the 8 waves hold every wave's issue for ~1000 cycles with no MFMA behind them.
-        auto piece = [&](int kt, int buf, int j) {
-            unsigned char *base = smem + buf * LSTAGE + (wave * 4) * 1024;
-            const unsigned adv = (unsigned)kt * ROWB;
-            if (j < 4)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + j * 1024), 16, voffX[j],
-                                                         sx0 + adv, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + LX_BYTES + (j - 4) * 1024),
-                                                         16, voffW[j - 4], sw0 + adv, 0, 0);
-        };
+    auto piece = [&](int kt, int buf, int j) {                 // one 1 KiB DMA piece of a stage: j < 4 X, else W
+        unsigned char *base = smem + buf * LSTAGE + (wave * 4) * 1024;
+        const unsigned adv = (unsigned)kt * ROWB;
+        if (j < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + j * 1024), 16, voffX[j],
+                                                     sx0 + adv, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + LX_BYTES + (j - 4) * 1024),
+                                                     16, voffW[j - 4], sw0 + adv, 0, 0);
+    };
 #define IVR_ROW(XF, WF, MT)                                                                                \
     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) mma_chunk<T>(WF[nt], XF[MT], acc[nt][MT]);            \
     __builtin_amdgcn_sched_barrier(0);
@@ -578,120 +554,64 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[1]) : "v"(ADDR), "n"(O0 + 2048));               \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[2]) : "v"(ADDR), "n"(O0 + 4096));               \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[3]) : "v"(ADDR), "n"(O0 + 6144));
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        IVR_STAMP(1)
-        if (KT > 1) stage(1, 1);
-        {
-            const unsigned wa = foW[0], xa = foX[0];
-            u32x4 *xlo = xa0, *xhi = xa0 + 4;
-            IVR_RD4(wa0, wa, 0)
-            IVR_RD4(xlo, xa, 0)
-            IVR_RD4(xhi, xa, 8192)
-        }
-        for (int kt = 0; kt < KT; ++kt) {
-            const unsigned boff = (kt & 1) * LSTAGE, noff = ((kt + 1) & 1) * LSTAGE;
-            const bool tail = kt >= 1 && kt + 1 < KT;       // last two pieces of stage kt+1 (the first stage-1 DMA is whole)
-            const bool more = kt + 2 < KT, next = kt + 1 < KT;
-            u32x4 *x1lo = xa1, *x1hi = xa1 + 4, *x0lo = xa0, *x0hi = xa0 + 4;
-            const unsigned wa = foW[1] + boff, xa = foX[1] + boff;
-            IVR_BIG_WAIT(4)                 // W + first four X fragments of set 0
-            IVR_ROW(xa0, wa0, 0)
-            if (tail) piece(kt + 1, (kt + 1) & 1, 6);
-            IVR_ROW(xa0, wa0, 1)
-            IVR_RD4(wa1, wa, 0)
-            IVR_ROW(xa0, wa0, 2)
-            if (tail) piece(kt + 1, (kt + 1) & 1, 7);
-            IVR_ROW(xa0, wa0, 3)
-            IVR_RD4(x1lo, xa, 0)
-            IVR_BIG_WAIT(8)                 // all of set 0
-            IVR_ROW(xa0, wa0, 4)
-            IVR_ROW(xa0, wa0, 5)
-            IVR_RD4(x1hi, xa, 8192)
-            IVR_ROW(xa0, wa0, 6)
-            IVR_ROW(xa0, wa0, 7)
-            IVR_BIG_WAIT(0)                 // this wave has read everything it needs from the stage's buffer
-            const unsigned nwa = foW[0] + noff, nxa = foX[0] + noff;
-            if (next) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            IVR_ROW(xa1, wa1, 0)
-            if (more) piece(kt + 2, kt & 1, 0);
-            IVR_ROW(xa1, wa1, 1)
-            if (next) { IVR_RD4(wa0, nwa, 0) }
-            if (more) piece(kt + 2, kt & 1, 4);
-            IVR_ROW(xa1, wa1, 2)
-            if (more) piece(kt + 2, kt & 1, 1);
-            IVR_ROW(xa1, wa1, 3)
-            if (next) { IVR_RD4(x0lo, nxa, 0) }
-            if (more) piece(kt + 2, kt & 1, 5);
-            IVR_ROW(xa1, wa1, 4)
-            if (more) piece(kt + 2, kt & 1, 2);
-            IVR_ROW(xa1, wa1, 5)
-            if (next) { IVR_RD4(x0hi, nxa, 8192) }
-            IVR_ROW(xa1, wa1, 6)
-            if (more) piece(kt + 2, kt & 1, 3);
-            IVR_ROW(xa1, wa1, 7)
-        }
-        IVR_BIG_WAIT(0)
-        IVR_STAMP(2)
+#define IVR_LGKM(N)                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 xa0[8], wa0[4], xa1[8], wa1[4];
+    u32x4 *x0lo = xa0, *x0hi = xa0 + 4, *x1lo = xa1, *x1hi = xa1 + 4;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    IVR_STAMP(1)
+    if (KT > 1) stage(1, 1);
+    IVR_RD4(wa0, foW[0], 0)
+    IVR_RD4(x0lo, foX[0], 0)
+    IVR_RD4(x0hi, foX[0], 8192)
+    for (int kt = 0; kt < KT; ++kt) {
+        const unsigned boff = (kt & 1) * LSTAGE, noff = ((kt + 1) & 1) * LSTAGE;
+        const bool tail = kt >= 1 && kt + 1 < KT;       // last two pieces of stage kt+1 (the first stage-1 DMA went out whole)
+        const bool more = kt + 2 < KT, next = kt + 1 < KT;
+        const unsigned wa = foW[1] + boff, xa = foX[1] + boff, nwa = foW[0] + noff, nxa = foX[0] + noff;
+        IVR_LGKM(4)                     // W + first four X fragments of set 0
+        IVR_ROW(xa0, wa0, 0)
+        if (tail) piece(kt + 1, (kt + 1) & 1, 6);
+        IVR_ROW(xa0, wa0, 1)
+        IVR_RD4(wa1, wa, 0)
+        IVR_ROW(xa0, wa0, 2)
+        if (tail) piece(kt + 1, (kt + 1) & 1, 7);
+        IVR_ROW(xa0, wa0, 3)
+        IVR_RD4(x1lo, xa, 0)
+        IVR_LGKM(8)                     // all of set 0
+        IVR_ROW(xa0, wa0, 4)
+        IVR_ROW(xa0, wa0, 5)
+        IVR_RD4(x1hi, xa, 8192)
+        IVR_ROW(xa0, wa0, 6)
+        IVR_ROW(xa0, wa0, 7)
+        IVR_LGKM(0)                     // this wave has read everything it needs from the stage's buffer
+        if (next) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        IVR_ROW(xa1, wa1, 0)
+        if (more) piece(kt + 2, kt & 1, 0);
+        IVR_ROW(xa1, wa1, 1)
+        if (next) { IVR_RD4(wa0, nwa, 0) }
+        if (more) piece(kt + 2, kt & 1, 4);
+        IVR_ROW(xa1, wa1, 2)
+        if (more) piece(kt + 2, kt & 1, 1);
+        IVR_ROW(xa1, wa1, 3)
+        if (next) { IVR_RD4(x0lo, nxa, 0) }
+        if (more) piece(kt + 2, kt & 1, 5);
+        IVR_ROW(xa1, wa1, 4)
+        if (more) piece(kt + 2, kt & 1, 2);
+        IVR_ROW(xa1, wa1, 5)
+        if (next) { IVR_RD4(x0hi, nxa, 8192) }
+        IVR_ROW(xa1, wa1, 6)
+        if (more) piece(kt + 2, kt & 1, 3);
+        IVR_ROW(xa1, wa1, 7)
+    }
+    IVR_LGKM(0)
+    IVR_STAMP(2)
 #undef IVR_ROW
 #undef IVR_RD4
-    } else if (PIPE == 1) {
-        // software pipeline across the barrier: set 0 of stage kt+1 is read under the second half of stage kt's MFMAs, so
-        // no MFMA ever waits for a fragment read that was issued after a barrier.  The counted wait + barrier sits in the
-        // MIDDLE of the stage (all waves have then read both sets of stage kt, so its buffer can take the DMA of stage kt+2).
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (KT > 1) stage(1, 1);
-        {
-            const unsigned boff = 0;
-            IVR_BIG_READ(0, xa0, wa0)
-        }
-        for (int kt = 0; kt < KT; ++kt) {
-            const unsigned boff = (kt & 1) * LSTAGE;
-            IVR_BIG_WAIT(4)                 // W + first four X fragments of set 0
-            IVR_BIG_MMA(xa0, wa0, 0)
-            IVR_BIG_READ(1, xa1, wa1)
-            IVR_BIG_WAIT(12)                // all of set 0 (set 1 still in flight)
-            IVR_BIG_MMA(xa0, wa0, 4)
-            IVR_BIG_WAIT(0)                 // this wave has read everything it needs from the stage's buffer
-            if (kt + 1 < KT) {
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                if (kt + 2 < KT) stage(kt + 2, kt & 1);
-                const unsigned boff = ((kt + 1) & 1) * LSTAGE;
-                IVR_BIG_READ(0, xa0, wa0)
-            }
-            IVR_BIG_MMA(xa1, wa1, 0)
-            IVR_BIG_MMA(xa1, wa1, 4)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        IVR_BIG_WAIT(0)
-    } else {
-    stage(0, 0);
-    for (int kt = 0; kt < KT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
-        const unsigned boff = (kt & 1) * LSTAGE;
-        // two fragment sets: the 12 reads of the second half-step are issued under the first half-step's MFMAs
-        IVR_BIG_READ(0, xa0, wa0)
-        IVR_BIG_WAIT(4)                 // W + first four X fragments of set 0
-        IVR_BIG_MMA(xa0, wa0, 0)
-        IVR_BIG_READ(1, xa1, wa1)
-        IVR_BIG_WAIT(12)                // all of set 0 (set 1 still in flight)
-        IVR_BIG_MMA(xa0, wa0, 4)
-        IVR_BIG_WAIT(4)
-        IVR_BIG_MMA(xa1, wa1, 0)
-        IVR_BIG_WAIT(0)
-        IVR_BIG_MMA(xa1, wa1, 4)
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef IVR_GEMM_STAMPS
-        if (kt == 0) { IVR_STAMP(1) }
-#endif
-    }
-    IVR_STAMP(2)
-    }
-#undef IVR_BIG_MMA
-#undef IVR_BIG_WAIT
-#undef IVR_BIG_READ
+#undef IVR_LGKM
 
     if (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_RESID) && g.wide_epi) {
         __builtin_amdgcn_s_barrier();                         // every wave has read its last fragments
@@ -777,673 +697,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     IVR_STAMP(3)
 #endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// GEMM, large tile + deep ring: the 256 x 256 tile of gemm_big_kernel with the K step halved to 64 bytes per row so that
-// FOUR stages (32 KiB each) fit the 128 KiB of LDS and the LDS-DMA runs three stages (96 KiB) ahead instead of one.
-//   * LDS rows are 64 B; chunk c of row r sits at position c ^ ((r >> 1) & 3) (conflict-free for ds_read_b128, checked by
-//     enumeration of the four 16-lane groups); one DMA piece is 16 rows x 64 B, lane l -> row l >> 2, position l & 3.
-//   * software pipeline: the fragments of stage s+1 are read while the second half of stage s's MFMAs runs; the counted
-//     wait + barrier for stage s+1 therefore sits in the MIDDLE of step s, and the DMA for stage s+4 is issued right after
-//     it into the slot of stage s (every wave read its stage-s fragments before that barrier).
-//   * nothing else touches the vector-memory counter inside the K loop, so vmcnt(8) = "stages s+2, s+3 may stay in flight"
-//     is exact (4 pieces per wave per stage).
-// ---------------------------------------------------------------------------------------------
-constexpr int HROWB = 64, HX_BYTES = LBM * HROWB, HSTAGE = 2 * HX_BYTES, BIG32_LDS = 4 * HSTAGE;   // 128 KiB
-
-template <typename T, int EPI, int ACT>
-__global__ __launch_bounds__(512, 2) void gemm_big32_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
-    int tm, tn;
-    {
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;
-        if (i >= lx * NT) return;
-        const int gm = g.group_m;
-        const int per = gm * NT, grp = i / per, within = i - grp * per;
-        const int gme = min(gm, lx - grp * gm);
-        tm = xcd + 8 * (grp * gm + within % gme);
-        tn = within / gme;
-    }
-    const int m0 = tm * LBM, n0 = tn * LBN;
-    constexpr int EPR = HROWB / (int)sizeof(T);          // elements of K per stage (32 bf16 / 16 f32)
-    const int KT = g.K / EPR;                            // host guarantees KT even and >= 4
-    const unsigned lds0 = (unsigned)(size_t)smem;
-
-    // 16 + 16 pieces of 1 KiB per stage (16 rows x 64 B each); wave w issues pieces 2w, 2w+1 of X and of W
-    unsigned voffX[2], voffW[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rr = lane >> 2, r = 16 * (wave * 2 + j) + rr, c = (lane & 3) ^ ((rr >> 1) & 3);
-        voffX[j] = (unsigned)(r * g.lda) * (unsigned)sizeof(T) + c * 16;
-        voffW[j] = (unsigned)(r * g.ldw) * (unsigned)sizeof(T) + c * 16;
-    }
-    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.A), 0, (int)((int64_t)g.M * g.lda * sizeof(T)), 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * sizeof(T)), 0x00020000);
-    const unsigned sx0 = (unsigned)m0 * (unsigned)g.lda * (unsigned)sizeof(T), sw0 = (unsigned)n0 * (unsigned)g.ldw * (unsigned)sizeof(T);
-    auto stage = [&](int kt) {
-        unsigned char *base = smem + (kt & 3) * HSTAGE + (wave * 2) * 1024;
-        const unsigned adv = (unsigned)kt * HROWB;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + j * 1024), 16, voffX[j],
-                                                     sx0 + adv, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + HX_BYTES + j * 1024), 16,
-                                                     voffW[j], sw0 + adv, 0, 0);
-        }
-    };
-    // fragment of a 16-row tile: row lane & 15, logical chunk lane >> 4 -> position (lane >> 4) ^ ((row >> 1) & 3)
-    const unsigned fo = (lane & 15) * HROWB + (((lane >> 4) ^ ((lane >> 1) & 3)) << 4);
-    const unsigned foX = lds0 + (wm * 128) * HROWB + fo, foW = lds0 + HX_BYTES + (wn * 64) * HROWB + fo;
-
-    f32x4 acc[4][8];   // [nt][mt]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#define IVR_B32_READ(SLOT, XF, WF)                                                                         \
-    {                                                                                                      \
-        const unsigned xa = foX + (SLOT) * HSTAGE, wa = foW + (SLOT) * HSTAGE;                             \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(WF[0]) : "v"(wa));                                       \
-        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(WF[1]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(WF[2]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(WF[3]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(XF[0]) : "v"(xa));                                       \
-        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(XF[1]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(XF[2]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(XF[3]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(XF[4]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(XF[5]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(XF[6]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(XF[7]) : "v"(xa));                           \
-    }
-#define IVR_B32_MMA(XF, WF, LO)                                                                            \
-    _Pragma("unroll") for (int mt = LO; mt < LO + 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) \
-        mma_chunk<T>(WF[nt], XF[mt], acc[nt][mt]);
-#define IVR_B32_LGKM(N)                                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
-    __builtin_amdgcn_sched_barrier(0);
-// one K step: first half of the MFMAs, counted wait + barrier for stage S+1, DMA for stage S+4, fragments of S+1, second half
-#define IVR_B32_STEP(S, CX, CW, NX, NW)                                                                    \
-    {                                                                                                      \
-        IVR_B32_MMA(CX, CW, 0)                                                                             \
-        if ((S) + 1 < KT) {                                                                                \
-            if ((S) + 3 < KT) wait_vm_barrier<8>();                                                        \
-            else if ((S) + 2 < KT) wait_vm_barrier<4>();                                                   \
-            else wait_vm_barrier<0>();                                                                     \
-            if ((S) + 4 < KT) stage((S) + 4);                                                              \
-            IVR_B32_READ(((S) + 1) & 3, NX, NW)                                                            \
-        }                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        IVR_B32_MMA(CX, CW, 4)                                                                             \
-        IVR_B32_LGKM(0)                                                                                    \
-    }
-
-    u32x4 ax[8], aw[4], bx[8], bw[4];
-    stage(0);
-    stage(1);
-    stage(2);
-    stage(3);
-    wait_vm_barrier<12>();            // stage 0 landed (stages 1..3 = 12 pieces may stay in flight)
-    IVR_B32_READ(0, ax, aw)
-    IVR_B32_LGKM(0)
-    for (int kt = 0; kt < KT; kt += 2) {
-        IVR_B32_STEP(kt, ax, aw, bx, bw)
-        IVR_B32_STEP(kt + 1, bx, bw, ax, aw)
-    }
-#undef IVR_B32_READ
-#undef IVR_B32_MMA
-#undef IVR_B32_LGKM
-#undef IVR_B32_STEP
-
-    // epilogue in two halves of four row tiles (keeps the batched residual loads at 64 registers)
-    int ncol[4];
-    bool nok[4];
-    float4 bv[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        ncol[t] = n0 + wn * 64 + t * 16 + 4 * (lane >> 4);
-        nok[t] = ncol[t] < g.N;
-        ncol[t] = min(ncol[t], g.N - 4);
-        bv[t] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + ncol[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        int mrow[4];
-        bool mok[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            mrow[t] = m0 + wm * 128 + (half * 4 + t) * 16 + (lane & 15);
-            mok[t] = mrow[t] < g.M;
-            mrow[t] = min(mrow[t], g.M - 1);
-        }
-        if (EPI == EPI_RESID || EPI == EPI_PATCH) {
-            float4 rv[4][4];
-            float *rowp[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if (EPI == EPI_RESID) {
-                    rowp[mt] = g.resid + (int64_t)mrow[mt] * g.ldr;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) rv[mt][nt] = *reinterpret_cast<const float4 *>(rowp[mt] + ncol[nt]);
-                } else {
-                    const int img = mrow[mt] / g.G2, pch = mrow[mt] % g.G2;
-                    rowp[mt] = g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        rv[mt][nt] = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol[nt]);
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    float4 r = rv[mt][nt];
-                    const f32x4 a = acc[nt][half * 4 + mt];
-                    r.x += a[0] + bv[nt].x;
-                    r.y += a[1] + bv[nt].y;
-                    r.z += a[2] + bv[nt].z;
-                    r.w += a[3] + bv[nt].w;
-                    if (mok[mt] && nok[nt]) *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
-                }
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const f32x4 a = acc[nt][half * 4 + mt];
-                    float v[4] = {a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w};
-                    if (ACT >= 0) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
-                    }
-                    if (mok[mt] && nok[nt]) {
-                        if (EPI == EPI_STORE)
-                            El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt], v);
-                        else
-                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt]) =
-                                make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// GEMM, wide tile with two independent workgroups per CU: 256 x 128 tile, 4 waves as 2 x 2 with 128 x 64 per wave (the
-// big kernel's wave tile), K step of 64 bytes per row, THREE stages of 24 KiB = 72 KiB of LDS, so two workgroups share a
-// CU and their barrier phases decouple (one's fragment reads and waits sit under the other's MFMAs), while each keeps
-// two stages of LDS-DMA in flight.
-//   * LDS rows are 64 B; chunk c of row r sits at position c ^ ((r >> 1) & 3) (conflict-free for ds_read_b128, checked by
-//     enumeration of the four 16-lane groups); one DMA piece is 16 rows x 64 B, lane l -> row l >> 2, position l & 3.
-//   * software pipeline: the fragments of stage s+1 are read while the second half of stage s's MFMAs runs; the counted
-//     wait + barrier for stage s+1 therefore sits in the MIDDLE of step s, and the DMA for stage s+3 is issued right after
-//     it into the slot of stage s (every wave read its stage-s fragments before that barrier).
-//   * nothing else touches the vector-memory counter inside the K loop, so vmcnt(6) = "stage s+2 may stay in flight" is exact
-//     (6 pieces per wave per stage).
-// ---------------------------------------------------------------------------------------------
-constexpr int WBN = 128, WW_BYTES = WBN * HROWB, WSTAGE = HX_BYTES + WW_BYTES, WIDE_LDS = 3 * WSTAGE;   // 72 KiB
-
-template <typename T, int EPI, int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + WBN - 1) / WBN;
-    int tm, tn;
-    {
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;
-        if (i >= lx * NT) return;
-        const int gm = g.group_m;
-        const int per = gm * NT, grp = i / per, within = i - grp * per;
-        const int gme = min(gm, lx - grp * gm);
-        tm = xcd + 8 * (grp * gm + within % gme);
-        tn = within / gme;
-    }
-    const int m0 = tm * LBM, n0 = tn * WBN;
-    constexpr int EPR = HROWB / (int)sizeof(T);          // elements of K per stage (32 bf16 / 16 f32)
-    const int KT = g.K / EPR;                            // host guarantees KT even and >= 4
-    const unsigned lds0 = (unsigned)(size_t)smem;
-
-    // 16 + 8 pieces of 1 KiB per stage (16 rows x 64 B each); wave w issues X pieces 4w..4w+3 and W pieces 2w, 2w+1
-    unsigned voffX[4], voffW[2];
-    {
-        const int rr = lane >> 2, c = (lane & 3) ^ ((rr >> 1) & 3);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) voffX[j] = (unsigned)((16 * (wave * 4 + j) + rr) * g.lda) * (unsigned)sizeof(T) + c * 16;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) voffW[j] = (unsigned)((16 * (wave * 2 + j) + rr) * g.ldw) * (unsigned)sizeof(T) + c * 16;
-    }
-    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.A), 0, (int)((int64_t)g.M * g.lda * sizeof(T)), 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * sizeof(T)), 0x00020000);
-    const unsigned sx0 = (unsigned)m0 * (unsigned)g.lda * (unsigned)sizeof(T), sw0 = (unsigned)n0 * (unsigned)g.ldw * (unsigned)sizeof(T);
-    auto stage = [&](int kt, int slot) {
-        unsigned char *base = smem + slot * WSTAGE;
-        const unsigned adv = (unsigned)kt * HROWB;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + (wave * 4 + j) * 1024), 16,
-                                                     voffX[j], sx0 + adv, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + HX_BYTES + (wave * 2 + j) * 1024),
-                                                     16, voffW[j], sw0 + adv, 0, 0);
-    };
-    // fragment of a 16-row tile: row lane & 15, logical chunk lane >> 4 -> position (lane >> 4) ^ ((row >> 1) & 3)
-    const unsigned fo = (lane & 15) * HROWB + (((lane >> 4) ^ ((lane >> 1) & 3)) << 4);
-    const unsigned foX = lds0 + (wm * 128) * HROWB + fo, foW = lds0 + HX_BYTES + (wn * 64) * HROWB + fo;
-
-    f32x4 acc[4][8];   // [nt][mt]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#define IVR_B32_READ(SLOT, XF, WF)                                                                         \
-    {                                                                                                      \
-        const unsigned xa = foX + (SLOT) * WSTAGE, wa = foW + (SLOT) * WSTAGE;                             \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(WF[0]) : "v"(wa));                                       \
-        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(WF[1]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(WF[2]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(WF[3]) : "v"(wa));                           \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(XF[0]) : "v"(xa));                                       \
-        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(XF[1]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(XF[2]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(XF[3]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(XF[4]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(XF[5]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(XF[6]) : "v"(xa));                           \
-        asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(XF[7]) : "v"(xa));                           \
-    }
-#define IVR_B32_MMA(XF, WF, LO)                                                                            \
-    _Pragma("unroll") for (int mt = LO; mt < LO + 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) \
-        mma_chunk<T>(WF[nt], XF[mt], acc[nt][mt]);
-#define IVR_B32_LGKM(N)                                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
-    __builtin_amdgcn_sched_barrier(0);
-// one K step: first half of the MFMAs, counted wait + barrier for stage S+1, DMA for stage S+3 into the slot of stage S,
-// fragments of S+1, second half.  sl = slot of stage S.
-#define IVR_B32_STEP(S, CX, CW, NX, NW)                                                                    \
-    {                                                                                                      \
-        IVR_B32_MMA(CX, CW, 0)                                                                             \
-        const int nsl = sl == 2 ? 0 : sl + 1;                                                              \
-        if ((S) + 1 < KT) {                                                                                \
-            if ((S) + 2 < KT) wait_vm_barrier<6>();                                                        \
-            else wait_vm_barrier<0>();                                                                     \
-            if ((S) + 3 < KT) stage((S) + 3, sl);                                                          \
-            IVR_B32_READ(nsl, NX, NW)                                                                      \
-        }                                                                                                  \
-        sl = nsl;                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        IVR_B32_MMA(CX, CW, 4)                                                                             \
-        IVR_B32_LGKM(0)                                                                                    \
-    }
-
-    u32x4 ax[8], aw[4], bx[8], bw[4];
-    stage(0, 0);
-    stage(1, 1);
-    stage(2, 2);
-    wait_vm_barrier<12>();            // stage 0 landed (stages 1, 2 = 12 pieces may stay in flight)
-    int sl = 0;
-    IVR_B32_READ(0, ax, aw)
-    IVR_B32_LGKM(0)
-    for (int kt = 0; kt < KT; kt += 2) {
-        IVR_B32_STEP(kt, ax, aw, bx, bw)
-        IVR_B32_STEP(kt + 1, bx, bw, ax, aw)
-    }
-#undef IVR_B32_READ
-#undef IVR_B32_MMA
-#undef IVR_B32_LGKM
-#undef IVR_B32_STEP
-
-    if (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_RESID) && g.wide_epi) {
-        __builtin_amdgcn_s_barrier();                         // every wave has read its last fragments
-        wide_epilogue<T, EPI, ACT>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
-        return;
-    }
-    // epilogue in two halves of four row tiles (keeps the batched residual loads at 64 registers)
-    int ncol[4];
-    bool nok[4];
-    float4 bv[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        ncol[t] = n0 + wn * 64 + t * 16 + 4 * (lane >> 4);
-        nok[t] = ncol[t] < g.N;
-        ncol[t] = min(ncol[t], g.N - 4);
-        bv[t] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + ncol[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        int mrow[4];
-        bool mok[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            mrow[t] = m0 + wm * 128 + (half * 4 + t) * 16 + (lane & 15);
-            mok[t] = mrow[t] < g.M;
-            mrow[t] = min(mrow[t], g.M - 1);
-        }
-        if (EPI == EPI_RESID || EPI == EPI_PATCH) {
-            float4 rv[4][4];
-            float *rowp[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if (EPI == EPI_RESID) {
-                    rowp[mt] = g.resid + (int64_t)mrow[mt] * g.ldr;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) rv[mt][nt] = *reinterpret_cast<const float4 *>(rowp[mt] + ncol[nt]);
-                } else {
-                    const int img = mrow[mt] / g.G2, pch = mrow[mt] % g.G2;
-                    rowp[mt] = g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        rv[mt][nt] = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol[nt]);
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    float4 r = rv[mt][nt];
-                    const f32x4 a = acc[nt][half * 4 + mt];
-                    r.x += a[0] + bv[nt].x;
-                    r.y += a[1] + bv[nt].y;
-                    r.z += a[2] + bv[nt].z;
-                    r.w += a[3] + bv[nt].w;
-                    if (mok[mt] && nok[nt]) *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
-                }
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const f32x4 a = acc[nt][half * 4 + mt];
-                    float v[4] = {a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w};
-                    if (ACT >= 0) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
-                    }
-                    if (mok[mt] && nok[nt]) {
-                        if (EPI == EPI_STORE)
-                            El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt], v);
-                        else
-                            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)mrow[mt] * g.ldo + ncol[nt]) =
-                                make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                }
-        }
-    }
-}
-
-// the i-th tile of a persistent workgroup (used by the experimental stream kernel below)
-struct TileWalk {      // the i-th tile of this workgroup
-    int MT, NT, mode, x, j, J, G, b;
-    __device__ void init(int M, int N, int bm, int bn) {
-        MT = (M + bm - 1) / bm;
-        NT = (N + bn - 1) / bn;
-        b = blockIdx.x;
-        G = gridDim.x;
-        mode = (G % 8 == 0 && MT >= 16) ? 1 : 0;
-        x = b & 7;
-        j = b >> 3;
-        J = G >> 3;
-    }
-    __device__ int count() const {
-        if (mode == 0) {
-            const int n = MT * NT;
-            return n > b ? (n - b + G - 1) / G : 0;
-        }
-        const int panels = MT > x ? (MT - x + 7) / 8 : 0;
-        const int n = panels * NT;
-        return n > j ? (n - j + J - 1) / J : 0;
-    }
-    __device__ void get(int i, int &tm, int &tn) const {
-        if (mode == 0) {
-            const int t = b + i * G;
-            tm = t / NT;
-            tn = t % NT;
-        } else {
-            const int idx = j + i * J;
-            tm = x + 8 * (idx / NT);
-            tn = idx % NT;
-        }
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
-// GEMM, stream version: one persistent 4-wave workgroup per CU (one wave per SIMD), 128 x 128 tile, and a
-// 4-slot LDS-DMA ring kept THREE K steps (96 KiB) ahead of the MFMAs, continuously across tile boundaries.
-// Nothing the compiler can see ever loads from global memory, so it inserts no s_waitcnt vmcnt of its own:
-//   * operand tiles: global_load_lds (8 x 1 KiB pieces per wave per stage);
-//   * bias / residual / position rows: inline-asm global_load_dwordx4 issued at the START of a tile and consumed in its
-//     epilogue (>= 4 counted waits later, so they have retired);
-//   * outputs: raw buffer stores - always issued, out-of-range lanes are clipped by the descriptor - so the number
-//     of vector-memory operations per tile is exact and every wait can be COUNTED:
-//       at the top of K step s the wave may leave outstanding everything younger than stage s's DMA, i.e. the two
-//       younger stages (16 pieces) + the previous tile's 16 stores + this tile's NL tile-start loads, depending on the
-//       position c of the step in its tile:   c <= 2: 32 + NL (first tile: 16 + NL)      c >= 3: 16.
-// ---------------------------------------------------------------------------------------------
-constexpr int SSTAGES = 4, STILE = 2 * TILE_BYTES, STREAM_LDS = SSTAGES * STILE;   // 128 KiB
-
-
-template <typename T, int EPI, int ACT, bool HASBIAS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_stream_kernel(GemmArgs g) {
-    constexpr int NL = (HASBIAS ? 4 : 0) + ((EPI == EPI_RESID || EPI == EPI_PATCH) ? 16 : 0);
-    static_assert(32 + NL <= 63, "vmcnt is a 6-bit counter");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: keeps the DMA addressing scalar
-    const int wm = wave >> 1, wn = wave & 1;
-    constexpr int EPR = ROWB / (int)sizeof(T);
-    const int KT = g.K / EPR;                        // host guarantees KT >= 4
-    TileWalk tw;
-    tw.init(g.M, g.N, BM, BN);
-    const int ntiles = tw.count();
-    const int S = ntiles * KT;
-    if (S == 0) return;
-    const unsigned lds0 = (unsigned)(size_t)smem;
-
-    // ---- producer: wave w moves X rows 32w..32w+31 and W rows 32w..32w+31 of every stage (4 + 4 pieces of 1 KiB) with
-    // buffer_load ... lds: the per-lane part of the address (row inside the tile, swizzled 16-byte chunk) is a constant
-    // voffset, everything that changes (tile origin, K step, ring slot) is SCALAR (soffset, M0): no vector ALU work per
-    // stage.  Rows past the end of a matrix read as zeros through the descriptor's bounds check.
-    const int prow = lane >> 3, pchunk = ((lane & 7) ^ (lane >> 3)) * 16;
-    unsigned voffX[4], voffW[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = 8 * (wave * 4 + q) + prow;
-        voffX[q] = (unsigned)(r * g.lda) * (unsigned)sizeof(T) + pchunk;
-        voffW[q] = (unsigned)(r * g.ldw) * (unsigned)sizeof(T) + pchunk;
-    }
-    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.A), 0, (int)((int64_t)g.M * g.lda * sizeof(T)), 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * sizeof(T)), 0x00020000);
-    int p_kt = 0, p_slot = 0, p_item = 0;
-    unsigned p_sx = 0, p_sw = 0;                      // scalar byte offsets of the tile being streamed
-    auto issue = [&]() {
-        if (p_kt == 0) {
-            int tm, tn;
-            tw.get(p_item, tm, tn);
-            p_sx = (unsigned)(tm * BM) * (unsigned)g.lda * (unsigned)sizeof(T);
-            p_sw = (unsigned)(tn * BN) * (unsigned)g.ldw * (unsigned)sizeof(T);
-        }
-        unsigned char *base = smem + p_slot * STILE + (wave * 4) * 1024;
-        const unsigned adv = (unsigned)p_kt * ROWB;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + q * 1024), 16, voffX[q],
-                                                     p_sx + adv, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + TILE_BYTES + q * 1024), 16,
-                                                     voffW[q], p_sw + adv, 0, 0);
-        }
-        if (++p_kt == KT) {
-            p_kt = 0;
-            ++p_item;
-        }
-        p_slot = (p_slot + 1) & (SSTAGES - 1);
-    };
-
-    // ---- consumer state: per-lane fragment offsets (operand, kk) inside a ring slot; tile rows as immediates
-    unsigned foX[2], foW[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const unsigned f = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
-        foX[kk] = lds0 + (wm * 64) * ROWB + f;
-        foW[kk] = lds0 + TILE_BYTES + (wn * 64) * ROWB + f;
-    }
-    // output descriptors: out-of-range rows/columns are clipped by num_records, never by exec
-    const unsigned out_elem = EPI == EPI_STORE ? (unsigned)sizeof(T) : 4u;
-    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        (EPI == EPI_RESID || EPI == EPI_PATCH) ? (void *)g.resid : g.out, 0,
-        (EPI == EPI_PATCH) ? (int)0x7fffffff
-                           : (int)min((int64_t)0x7fffffff, (int64_t)g.M * ((EPI == EPI_RESID) ? g.ldr : g.ldo) * out_elem),
-        0x00020000);
-    // tile-start loads land in the ACCUMULATOR half of the register file ("a" constraint): 80 registers that would
-    // otherwise push the MFMA accumulators out of the architectural VGPRs and back every K step
-    u32x4 bvr[4];          // bias quads of this lane's 4 column groups
-    u32x4 rvr[4][4];       // residual / position quads [mt][nt]
-    int mrow[4], ncol[4];
-    bool nok[4];
-
-    // Software pipeline (one wave per SIMD has nobody else to hide its LDS latency): the kk = 0 fragments of stage s+1 are
-    // read while the kk = 1 MFMAs of stage s run, so every ds_read burst sits under 16 MFMAs.  That needs stage s+1
-    // landed one half-step early: the counted wait + barrier sits in the MIDDLE of step s and waits for stage s+1,
-    // leaving stage s+2 (8 pieces) in flight; DMA for stage s+3 is issued right after it into the slot of stage s-1.
-    // Younger than stage s+1's DMA at that wait: stage s+2, and for the first two K steps of a tile also the previous
-    // tile's 16 stores and this tile's NL tile-start loads.  Two K steps per trip so the fragment sets ping-pong
-    // between two register groups with no copy of an in-flight register.
-#define IVR_READ_FRAGS(DSTX, DSTW, SLOT, KK)                                                                            \
-    {                                                                                                                   \
-        const unsigned xa_ = foX[KK] + (SLOT) * STILE, wa_ = foW[KK] + (SLOT) * STILE;                                  \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(DSTX[0]) : "v"(xa_));                                                 \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(DSTW[0]) : "v"(wa_));                                                 \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(DSTX[1]) : "v"(xa_));                                     \
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(DSTW[1]) : "v"(wa_));                                     \
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(DSTX[2]) : "v"(xa_));                                     \
-        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(DSTW[2]) : "v"(wa_));                                     \
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(DSTX[3]) : "v"(xa_));                                     \
-        asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(DSTW[3]) : "v"(wa_));                                     \
-    }
-#define IVR_MMA16(FX, FW)                                                                                               \
-    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                   \
-        mma_chunk<T>(FW[nt], FX[mt], acc[nt][mt]);
-#define IVR_LGKM(N)                                                                                                     \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                             \
-    __builtin_amdgcn_sched_barrier(0);
-
-    for (int q = 0; q < SSTAGES - 1 && q < S; ++q) issue();
-    int c_slot = 0, s = 0;
-    u32x4 ax[4], aw[4], bx[4], bw[4], gx[4], gw[4];     // A / B: kk = 0 sets (ping-pong), G: kk = 1 set
-    for (int item = 0; item < ntiles; ++item) {
-        // ---- tile-start loads (inline asm: invisible to the compiler's waitcnt pass, always issued, NL per wave)
-        {
-            int tm, tn;
-            tw.get(item, tm, tn);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                mrow[t] = tm * BM + wm * 64 + t * 16 + (lane & 15);
-                ncol[t] = tn * BN + wn * 64 + t * 16 + 4 * (lane >> 4);
-                nok[t] = ncol[t] < g.N;
-            }
-            if (HASBIAS) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bvr[t]) : "v"(g.bias + min(ncol[t], g.N - 4)));
-            }
-            if (EPI == EPI_RESID || EPI == EPI_PATCH) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const int mr = min(mrow[mt], g.M - 1);
-                    const float *rowp = EPI == EPI_RESID ? g.resid + (int64_t)mr * g.ldr : g.pos + (int64_t)(1 + mr % g.G2) * g.N;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(rvr[mt][nt]) : "v"(rowp + min(ncol[nt], g.N - 4)));
-                }
-            }
-        }
-        if (item == 0) {
-            // stage 0 must have landed before its first fragment read: younger than its DMA are stages 1, 2 and the loads
-            if (S > 2) wait_vm_barrier<16 + NL>(); else wait_vm_barrier<0>();
-            IVR_READ_FRAGS(ax, aw, 0, 0)
-        }
-        f32x4 acc[4][4];   // [nt][mt]
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        for (int kt = 0; kt < KT; kt += 2) {           // host guarantees KT even
-#pragma unroll
-            for (int half = 0; half < 2; ++half, ++s) {
-                const int c = kt + half;
-                const int nslot = (c_slot + 1) & (SSTAGES - 1);
-                // kk = 1 fragments of this stage, then the kk = 0 MFMAs (their operands were read one half-step ago)
-                IVR_READ_FRAGS(gx, gw, c_slot, 1)
-                IVR_LGKM(8)
-                if (half == 0) { IVR_MMA16(ax, aw) } else { IVR_MMA16(bx, bw) }
-                // stage s+1 for everybody (nothing to wait for after the last stage)
-                if (s + 1 < S) {
-                    if (s + 2 >= S) wait_vm_barrier<0>();
-                    else if (c >= 2) wait_vm_barrier<8>();
-                    else if (item == 0) wait_vm_barrier<8 + NL>();
-                    else wait_vm_barrier<24 + NL>();
-                    if (s + SSTAGES - 1 < S) issue();
-                    if (half == 0) { IVR_READ_FRAGS(bx, bw, nslot, 0) } else { IVR_READ_FRAGS(ax, aw, nslot, 0) }
-                    IVR_LGKM(8)
-                } else {
-                    IVR_LGKM(0)
-                }
-                IVR_MMA16(gx, gw)
-                c_slot = nslot;
-            }
-        }
-
-        // ---- epilogue.  The tile-start loads retired long ago (>= KT counted waits since); tell the compiler their
-        // registers are now defined, then exactly 16 buffer stores per wave.
-        if (HASBIAS) asm volatile("" : "+a"(bvr[0]), "+a"(bvr[1]), "+a"(bvr[2]), "+a"(bvr[3]));
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            if (EPI == EPI_RESID || EPI == EPI_PATCH)
-                asm volatile("" : "+a"(rvr[mt][0]), "+a"(rvr[mt][1]), "+a"(rvr[mt][2]), "+a"(rvr[mt][3]));
-            // row of the destination (EPI_PATCH scatters patch rows to token rows); rows >= M are clipped below
-            int64_t drow = mrow[mt];
-            if (EPI == EPI_PATCH) drow = (int64_t)(mrow[mt] / g.G2) * g.T + 1 + mrow[mt] % g.G2;
-            const bool mok = mrow[mt] < g.M;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
-                if (HASBIAS) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += __uint_as_float(bvr[nt][i]);
-                }
-                if (EPI == EPI_RESID || EPI == EPI_PATCH) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += __uint_as_float(rvr[mt][nt][i]);
-                }
-                if (ACT >= 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
-                }
-                const int ld = (EPI == EPI_RESID || EPI == EPI_PATCH) ? g.ldr : g.ldo;
-                // byte offset; 0xffffffff (clipped by the descriptor) for rows / columns outside the matrix
-                const int64_t off = (drow * ld + ncol[nt]) * (int64_t)out_elem;
-                const unsigned voff = (mok && nok[nt] && off < 0x7fffffff) ? (unsigned)off : 0xffffffffu;
-                if (EPI == EPI_STORE && sizeof(T) == 2) {
-                    u32x2 d = {ivr_pack_bf16x2(v[0], v[1]), ivr_pack_bf16x2(v[2], v[3])};
-                    __builtin_amdgcn_raw_buffer_store_b64(d, rs_out, voff, 0, 0);
-                } else {
-                    u32x4 d = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(d, rs_out, voff, 0, 0);
-                }
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1700,13 +953,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
     }
 }
 
-// kernel choice, overridable for A/B runs (default: 4 for large problems, else 0): IVR_GEMM=0 128x128 kernel, 4 256x256
-// kernel, 3 experimental stream kernel (persistent, 4-slot ring, counted waits, one 4-wave workgroup per CU)
-int ring_mode() {
+// kernel choice, overridable for A/B runs: IVR_GEMM=0 the 128 x 128 kernel, 4 the 256 x 256 kernel; default by problem size
+int gemm_mode() {
     static int v = -2;
     if (v == -2) {
         const char *e = getenv("IVR_GEMM");
-        v = (e && (e[0] == '0' || (e[0] >= '3' && e[0] <= '8'))) ? e[0] - '0' : -1;
+        v = (e && (e[0] == '0' || e[0] == '4')) ? e[0] - '0' : -1;
     }
     return v;
 }
@@ -1819,141 +1071,34 @@ __global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsi
 template <typename T, int EPI, int ACT>
 int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
-    int mode = ring_mode();
+    int mode = gemm_mode();
     // default (-1): the 256 x 256 kernel once it fills the chip, the 128 x 128 kernel for small problems
     if (mode < 0) mode = ((g.M + LBM - 1) / LBM) * ((g.N + LBN - 1) / LBN) >= 192 ? 4 : 0;
-    if (mode == 6 && (g.K / (HROWB / (int)sizeof(T))) >= 4 && (g.K / (HROWB / (int)sizeof(T))) % 2 == 0) {
+    static int group_env = -1, wide_env = -1;
+    if (group_env < 0) {
+        const char *e = getenv("IVR_GEMM_GROUP_M");
+        group_env = e ? std::max(1, atoi(e)) : 0;
+        e = getenv("IVR_GEMM_WIDE_EPI");
+        wide_env = e ? atoi(e) != 0 : 1;
+    }
+    GemmArgs ga = g;
+    if (mode == 4) {
         static bool attr_done = false;
         if (!attr_done) {
-            IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_wide_kernel<T, EPI, ACT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
+            IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS));
             attr_done = true;
         }
-        GemmArgs ga = g;
-        static int group_m = -1;
-        if (group_m < 0) {
-            const char *e = getenv("IVR_GEMM_GROUP_M");
-            group_m = e ? std::max(1, atoi(e)) : 0;
-        }
-        const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + WBN - 1) / WBN;
-        ga.group_m = group_m ? group_m : (NT <= 6 ? 2 : 8);
-        {
-            const char *e = getenv("IVR_GEMM_WIDE_EPI");
-            const bool wide = e ? atoi(e) != 0 : true;
-            const bool bias_ok = !g.bias || reinterpret_cast<uintptr_t>(g.bias) % 16 == 0;
-            if (EPI == EPI_STORE)
-                ga.wide_epi = wide && bias_ok && g.N % WBN == 0 && g.ldo % 8 == 0 && reinterpret_cast<uintptr_t>(g.out) % 16 == 0;
-            else if (EPI == EPI_RESID)
-                ga.wide_epi = wide && bias_ok && g.N % WBN == 0 && g.ldr % 4 == 0 && reinterpret_cast<uintptr_t>(g.resid) % 16 == 0;
-        }
-        const int grid = 8 * ((MT + 7) / 8) * NT;
-        hipLaunchKernelGGL((gemm_wide_kernel<T, EPI, ACT>), dim3(grid), dim3(256), WIDE_LDS, s, ga);
-        IVR_LAUNCH_CHECK();
-        return IVR_OK;
-    }
-    if (mode == 6) mode = 4;
-    if (mode == 5 && (g.K / (HROWB / (int)sizeof(T))) >= 4 && (g.K / (HROWB / (int)sizeof(T))) % 2 == 0) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big32_kernel<T, EPI, ACT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, BIG32_LDS));
-            attr_done = true;
-        }
-        GemmArgs ga = g;
-        static int group_m = -1;
-        if (group_m < 0) {
-            const char *e = getenv("IVR_GEMM_GROUP_M");
-            group_m = e ? std::max(1, atoi(e)) : 0;
-        }
         const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
-        ga.group_m = group_m ? group_m : (NT <= 3 ? 2 : 8);
-        const int grid = 8 * ((MT + 7) / 8) * NT;
-        hipLaunchKernelGGL((gemm_big32_kernel<T, EPI, ACT>), dim3(grid), dim3(512), BIG32_LDS, s, ga);
-        IVR_LAUNCH_CHECK();
-        return IVR_OK;
-    }
-    if (mode == 5) mode = 4;
-    if (mode == 4 || mode == 7 || mode == 8) {
-        GemmArgs ga = g;
-        static int group_m = -1;
-        if (group_m < 0) {
-            const char *e = getenv("IVR_GEMM_GROUP_M");
-            group_m = e ? std::max(1, atoi(e)) : 0;
-        }
-        const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
-        ga.group_m = group_m ? group_m : (NT <= 3 ? 2 : 8);     // measured: narrow outputs want short groups
-        static int stagger = -1;
-        if (stagger < 0) {
-            const char *e = getenv("IVR_GEMM_STAGGER");
-            stagger = e ? atoi(e) : 0;
-        }
-        ga.stagger = stagger;
-        static int wide = -1;
-        if (wide < 0) {
-            const char *e = getenv("IVR_GEMM_WIDE_EPI");
-            wide = e ? atoi(e) : 1;
-        }
+        ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 8);     // measured: narrow outputs want short groups
+        // the row-wide epilogue needs whole 64-column wave blocks and 16-byte aligned rows
+        const bool bias_ok = !g.bias || reinterpret_cast<uintptr_t>(g.bias) % 16 == 0;
         if (EPI == EPI_STORE)
-            ga.wide_epi = wide && g.N % LBN == 0 && g.ldo % 8 == 0 && reinterpret_cast<uintptr_t>(g.out) % 16 == 0;
+            ga.wide_epi = wide_env && bias_ok && g.N % LBN == 0 && g.ldo % 8 == 0 && reinterpret_cast<uintptr_t>(g.out) % 16 == 0;
         else if (EPI == EPI_RESID)
-            ga.wide_epi = wide && g.N % LBN == 0 && g.ldr % 4 == 0 && reinterpret_cast<uintptr_t>(g.resid) % 16 == 0;
-        if (ga.wide_epi && g.bias && reinterpret_cast<uintptr_t>(g.bias) % 16 != 0) ga.wide_epi = 0;
+            ga.wide_epi = wide_env && bias_ok && g.N % LBN == 0 && g.ldr % 4 == 0 && reinterpret_cast<uintptr_t>(g.resid) % 16 == 0;
         const int grid = 8 * ((MT + 7) / 8) * NT;
-        if (mode == 8) {
-            static bool attr_done = false;
-            if (!attr_done) {
-                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT, 2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS));
-                attr_done = true;
-            }
-            hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT, 2>), dim3(grid), dim3(512), BIG_LDS, s, ga);
-        } else if (mode == 7) {
-            static bool attr_done = false;
-            if (!attr_done) {
-                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS));
-                attr_done = true;
-            }
-            hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT, 1>), dim3(grid), dim3(512), BIG_LDS, s, ga);
-        } else {
-            static bool attr_done = false;
-            if (!attr_done) {
-                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT, 0>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS));
-                attr_done = true;
-            }
-            hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT, 0>), dim3(grid), dim3(512), BIG_LDS, s, ga);
-        }
-        IVR_LAUNCH_CHECK();
-        return IVR_OK;
-    }
-    // the stream kernel needs >= 4 K steps per tile, outputs below 2 GiB (32-bit buffer offsets) and enough tiles
-    const int64_t out_bytes = (int64_t)g.M * std::max(g.ldo, g.ldr) * 4;
-    const int kt_steps = g.K / (ROWB / (int)sizeof(T));
-    const bool fits32 = (int64_t)g.M * g.lda * (int64_t)sizeof(T) < 0x7fffffff && (int64_t)g.N * g.ldw * (int64_t)sizeof(T) < 0x7fffffff;
-    if (mode == 3 && kt_steps >= 4 && kt_steps % 2 == 0 && out_bytes < 0x7fffffff && fits32 && (EPI != EPI_PATCH || g.resid)) {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
-        const int grid = std::min(MT * NT, cus);
-        if (g.bias) {
-            static bool attr_done = false;
-            if (!attr_done) {
-                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_stream_kernel<T, EPI, ACT, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS));
-                attr_done = true;
-            }
-            hipLaunchKernelGGL((gemm_stream_kernel<T, EPI, ACT, true>), dim3(grid), dim3(256), STREAM_LDS, s, g);
-        } else {
-            static bool attr_done = false;
-            if (!attr_done) {
-                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_stream_kernel<T, EPI, ACT, false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS));
-                attr_done = true;
-            }
-            hipLaunchKernelGGL((gemm_stream_kernel<T, EPI, ACT, false>), dim3(grid), dim3(256), STREAM_LDS, s, g);
-        }
+        hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT>), dim3(grid), dim3(512), BIG_LDS, s, ga);
         IVR_LAUNCH_CHECK();
         return IVR_OK;
     }
@@ -1964,13 +1109,7 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
         attr_done = true;
     }
-    GemmArgs ga = g;
-    static int group_m = -1;
-    if (group_m < 0) {
-        const char *e = getenv("IVR_GEMM_GROUP_M");
-        group_m = e ? std::max(1, atoi(e)) : 8;
-    }
-    ga.group_m = group_m;
+    ga.group_m = group_env ? group_env : 8;
     const int grid = 8 * ((MT + 7) / 8) * NT;               // every XCD gets the same number of ids; surplus ones exit
     hipLaunchKernelGGL((gemm_kernel<T, EPI, ACT>), dim3(grid), dim3(256), GEMM_LDS, s, ga);
     IVR_LAUNCH_CHECK();
