@@ -953,6 +953,226 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const unsigned shor
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 attention, head-resident version (64 < T <= 640: ViT-L/14 T = 257, DINO T = 197, CLIP text T = 77): one workgroup per
+// (image, head[, query split]); the head's whole K and V (T x 64 bf16 each) are staged ONCE into LDS by LDS-DMA, then every
+// wave runs a flash loop over 32-key blocks for its own QC query tiles of 16.  Products are transposed as in the kernels
+// above (S^T = K Q^T, O^T = V^T P^T) so a query stays on one lane column.
+//   * K image: 128-B rows, 16-B chunk ch at position ch ^ (row & 7)  (conflict-free ds_read_b128 of the A fragments).
+//   * V image: row-major [key][64 dh]; the V^T fragments come out of it with ds_read_b64_tr_b16 (hardware transpose: the
+//     16 lanes of a group read a 4-key x 16-dh block, lane i receives column i).  32-B segment s of a row sits at position
+//     s ^ ((row >> 1) & 3): the 8 rows a 32-lane half touches land on distinct banks.
+//     Both swizzles are applied on the DMA *source* address (the LDS side of an LDS-DMA is lane-linear).
+//   * rows past T read as zeros (buffer descriptor bounds), so no garbage ever enters an MFMA.
+//   * the key order inside an O^T MFMA is permuted (element j of lane group g = key 16*(j>>2) + 4g + (j&3)) so that P goes
+//     from the S^T accumulators to the B operand with a bf16 pack and no cross-lane traffic; the tr reads follow the same order.
+//   * softmax in base 2 (one fma + v_exp per score); the running max is shared by the 4 lanes of a query through
+//     v_permlane32_swap / v_permlane16_swap; row sums stay lane-local until the end; the O rescale is skipped (exactly: the
+//     factor would be 1) in blocks where no query of the wave raised its maximum; masks only in the tail / diagonal blocks.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float vmax2(float a, float b) {                // plain v_max_f32 (fmaxf adds two canonicalising moves)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float quad_max(float x) {      // max over lanes c, c+16, c+32, c+48
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = vmax2(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return vmax2(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {      // no IEEE canonicalisation moves around it
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float quad_sum(float x) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <int QC>
+__global__ __launch_bounds__(384, 3) void attention_head_kernel(const unsigned short *__restrict__ qkv, unsigned short *__restrict__ att,
+                                                                int Tn, int D, int heads, int causal, int nsplit, int Tp) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    int b = blockIdx.x;
+    const int split = b % nsplit;
+    b /= nsplit;
+    const int h = b % heads, img = b / heads;
+    const int c = lane & 15, g = lane >> 4;
+    unsigned char *Ks = smem, *Vs = smem + Tp * 128;
+    const int64_t rs = 3 * (int64_t)D;                     // qkv row stride (elements)
+    const unsigned short *ibase = qkv + (int64_t)img * Tn * rs;
+    const unsigned rowB = (unsigned)rs * 2;
+
+    // ---- stage K and V of the head: pieces of 8 rows x 128 B, lane l -> row l >> 3, LDS slot l & 7
+    {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(ibase), 0, (int)((int64_t)Tn * rowB), 0x00020000);
+        const int r = lane >> 3, pos = lane & 7;
+        const int chK = pos ^ r;
+        const int chV = ((((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1));
+        const unsigned voffK = r * rowB + (unsigned)(D + h * 64) * 2 + chK * 16;
+        const unsigned voffV = r * rowB + (unsigned)(2 * D + h * 64) * 2 + chV * 16;
+        const int npieces = Tp >> 3;
+        for (int p = wave; p < npieces; p += nw) {
+            const unsigned soff = (unsigned)p * 8 * rowB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(Ks + p * 1024), 16, voffK, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(Vs + p * 1024), 16, voffV, soff, 0, 0);
+        }
+    }
+    // ---- this wave's query tiles
+    const int ntiles = (Tn + 15) >> 4, tps = (ntiles + nsplit - 1) / nsplit;
+    const int tend = min(ntiles, (split + 1) * tps), t0 = split * tps + wave * QC;
+    uint4 qf[2][QC];      // B operand of S^T: query = 16*(t0+qt) + c, dh = 32*ks + 8*g .. +7
+#pragma unroll
+    for (int qt = 0; qt < QC; ++qt) {
+        const int q = min(16 * (t0 + qt) + c, Tn - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks][qt] = *reinterpret_cast<const uint4 *>(ibase + q * rs + h * 64 + ks * 32 + g * 8);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t0 >= tend) return;                                // (no barrier below)
+    const int nq = min(QC, tend - t0);
+
+    f32x4 o[4][QC];       // O^T[16*nt + 4g + r][query c of tile qt]
+    float m[QC], l[QC];
+#pragma unroll
+    for (int qt = 0; qt < QC; ++qt) {
+        m[qt] = -INFINITY;
+        l[qt] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) o[nt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    // per-lane LDS offsets: K row c, chunk 4ks+g;  V row 4g + (c>>2) (+16 for the second half), segment nt, 8-B piece c&3
+    unsigned offK[2], offV[4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) offK[ks] = lds0 + c * 128 + (((4 * ks + g) ^ (c & 7)) << 4);
+    {
+        const int vr = 4 * g + (c >> 2), xr = (2 * g + (c >> 3)) & 3;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) offV[nt] = lds0 + Tp * 128 + vr * 128 + ((nt ^ xr) << 5) + (c & 3) * 8;
+    }
+    constexpr float L2E = 1.4426950408889634f;
+    const int kend = causal ? min(Tn, 16 * (t0 + nq)) : Tn;
+    for (int k0 = 0; k0 < kend; k0 += 32) {
+        const unsigned kb = (unsigned)k0 * 128;
+        // ---- fragments of the block: 4 K reads, 8 transposed V reads
+        uint4 kf[2][2];
+        uint2 vlo[4], vhi[4];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0][0]) : "v"(offK[0] + kb));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0][1]) : "v"(offK[1] + kb));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(kf[1][0]) : "v"(offK[0] + kb));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(kf[1][1]) : "v"(offK[1] + kb));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[nt]) : "v"(offV[nt] + kb));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(vhi[nt]) : "v"(offV[nt] + kb));
+        }
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S^T block = K Q^T : s[kt][qt], key = k0 + 16*kt + 4g + r, query = 16*qt + c
+        f32x4 s[2][QC];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QC; ++qt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[kt][0]), __builtin_bit_cast(bf16x8_t, qf[0][qt]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[kt][1]), __builtin_bit_cast(bf16x8_t, qf[1][qt]), acc, 0, 0, 0);
+                s[kt][qt] = acc;
+            }
+        if (k0 + 32 > Tn || (causal && k0 + 31 > 16 * t0)) {
+#pragma unroll
+            for (int qt = 0; qt < QC; ++qt) {
+                const int q = 16 * (t0 + qt) + c;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + kt * 16 + g * 4 + r;
+                        if (key >= Tn || (causal && key > q)) s[kt][qt][r] = -INFINITY;
+                    }
+            }
+        }
+        // ---- online softmax, base 2
+        float mn[QC];
+        bool grew = false;
+#pragma unroll
+        for (int qt = 0; qt < QC; ++qt) {
+            float mx = vmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
+            mx = vmax3(mx, s[0][qt][3], s[1][qt][0]);
+            mx = vmax3(mx, s[1][qt][1], s[1][qt][2]);
+            mx = quad_max(vmax2(mx, s[1][qt][3]));
+            mn[qt] = vmax2(m[qt], mx);
+            grew |= mn[qt] > m[qt];
+        }
+        if (__any(grew)) {
+#pragma unroll
+            for (int qt = 0; qt < QC; ++qt) {
+                const float alpha = __builtin_amdgcn_exp2f((m[qt] - mn[qt]) * L2E);      // m = -inf (first block) -> 0
+                m[qt] = mn[qt];
+                l[qt] *= alpha;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    o[nt][qt][0] *= alpha;
+                    o[nt][qt][1] *= alpha;
+                    o[nt][qt][2] *= alpha;
+                    o[nt][qt][3] *= alpha;
+                }
+            }
+        }
+        uint4 pf[QC];     // P^T fragments (B operand of O^T)
+#pragma unroll
+        for (int qt = 0; qt < QC; ++qt) {
+            const float mb = -m[qt] * L2E;
+            float pv[2][4], sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], L2E, mb));       // v_exp_f32; masked (-inf) -> 0
+                    sum += pv[kt][r];
+                }
+            l[qt] += sum;
+            pf[qt].x = ivr_pack_bf16x2(pv[0][0], pv[0][1]);
+            pf[qt].y = ivr_pack_bf16x2(pv[0][2], pv[0][3]);
+            pf[qt].z = ivr_pack_bf16x2(pv[1][0], pv[1][1]);
+            pf[qt].w = ivr_pack_bf16x2(pv[1][2], pv[1][3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const uint4 vf = make_uint4(vlo[nt].x, vlo[nt].y, vhi[nt].x, vhi[nt].y);
+#pragma unroll
+            for (int qt = 0; qt < QC; ++qt)
+                o[nt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[qt]), o[nt][qt], 0, 0, 0);
+        }
+    }
+    // ---- store: lane holds O[query 16*qt + c][dh 16*nt + 4g .. +3]
+#pragma unroll
+    for (int qt = 0; qt < QC; ++qt) {
+        const float inv = __builtin_amdgcn_rcpf(quad_sum(l[qt]));
+        const int q = 16 * (t0 + qt) + c;
+        if (qt < nq && q < Tn) {
+            unsigned short *op = att + ((int64_t)img * Tn + q) * D + h * 64 + g * 4;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float v[4] = {o[nt][qt][0] * inv, o[nt][qt][1] * inv, o[nt][qt][2] * inv, o[nt][qt][3] * inv};
+                El<unsigned short>::store4(op + nt * 16, v);
+            }
+        }
+    }
+}
+
 // kernel choice, overridable for A/B runs: IVR_GEMM=0 the 128 x 128 kernel, 4 the 256 x 256 kernel; default by problem size
 int gemm_mode() {
     static int v = -2;
@@ -1170,6 +1390,30 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
         return IVR_OK;
     }
     if (!f32) {
+        const int Tp = (int)ivr_round_up(T, 32);
+        static int head_env = -1;
+        if (head_env < 0) {
+            const char *e = getenv("IVR_ATTN_HEAD");
+            head_env = e ? atoi(e) : 1;
+        }
+        if (head_env && 2 * Tp * 128 <= 160 * 1024 && (int64_t)T * 3 * D * 2 < 0x7fffffff) {
+            // head-resident kernel: K and V of a head in LDS, QC query tiles of 16 per wave, at most 6 waves per workgroup
+            constexpr int QC = 3;
+            const int ntiles = (T + 15) / 16;
+            const int nsplit = ivr_ceil_div(ntiles, 6 * QC);
+            const int tps = ivr_ceil_div(ntiles, nsplit), nw = ivr_ceil_div(tps, QC);
+            const int lds = 2 * Tp * 128;
+            static int attr_lds = 0;
+            if (lds > attr_lds) {
+                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_head_kernel<QC>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                attr_lds = lds;
+            }
+            hipLaunchKernelGGL(attention_head_kernel<QC>, dim3((unsigned)((int64_t)n * heads * nsplit)), dim3(64 * nw), lds, s,
+                               (const unsigned short *)qkv, (unsigned short *)att, T, D, heads, causal, nsplit, Tp);
+            IVR_LAUNCH_CHECK();
+            return IVR_OK;
+        }
         const int nqb = (T + 63) / 64;
         const int64_t items = (int64_t)n * heads * nqb;
         hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * VT_BYTES, s,
