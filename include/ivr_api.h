@@ -97,7 +97,13 @@ int64_t ivr_preprocess_scratch_bytes(int n, int h, int w, int flags, int out_siz
 enum { IVR_ACT_QUICK_GELU = 0, IVR_ACT_GELU_ERF = 1 };
 enum { IVR_POOL_CLS_POSTLN_PROJ = 0, IVR_POOL_LN_ALL_CLS = 1, IVR_POOL_EOS_LN_PROJ = 2 };
 enum { IVR_KIND_VISION = 0, IVR_KIND_TEXT = 1 };
-enum { IVR_COMPUTE_BF16 = 0, IVR_COMPUTE_F32 = 1 /* verification mode: f32 MFMA, f32 activations */ };
+enum {
+    IVR_COMPUTE_BF16 = 0,
+    IVR_COMPUTE_F32 = 1, /* verification mode: f32 MFMA, f32 activations */
+    IVR_COMPUTE_FP8 = 2  /* BASELINE config 5: the four GEMMs of every block on the CDNA4 fp8 MFMA (e4m3 operands, per-output-
+                          * channel weight scales, f32 accumulate); patch embedding, attention products, LN, residual stream and
+                          * projection as in the bf16 mode */
+};
 
 typedef struct ivr_tower_desc {
     int kind, width, layers, heads, mlp, tokens, out_dim, act, pool;
@@ -133,6 +139,13 @@ int64_t ivr_tower_workspace_bytes(ivr_tower *t);
 int ivr_linear(ivr_ctx *ctx, int f32_mode, int epilogue, const void *x /*DEV*/, const void *w /*DEV*/,
                const float *bias /*DEV*/, int M, int N, int K, int act, void *out /*DEV*/, float *resid /*DEV*/,
                ivr_stream stream);
+
+/* fp8 variant of ivr_linear (the GEMM of IVR_COMPUTE_FP8): x DEV [M,K] and w DEV [N,K] are OCP e4m3 bytes, colscale DEV
+ * float32 [N] multiplies column n of x w^T before the bias (the weight's dequantisation scale; NULL = 1).  K % 128 == 0,
+ * N % 64 == 0.  epilogue 0: out = act(y) as bf16 (out_fp8 = 0) or saturated e4m3 (out_fp8 = 1); 1: resid += y. */
+int ivr_linear_fp8(ivr_ctx *ctx, int epilogue, const void *x /*DEV*/, const void *w /*DEV*/, const float *colscale /*DEV*/,
+                   const float *bias /*DEV*/, int M, int N, int K, int act, void *out /*DEV*/, int out_fp8,
+                   float *resid /*DEV*/, ivr_stream stream);
 
 /* ---- N2 / N3: row L2 normalisation -------------------------------------------------------------
  * Replaces FAISSRetriever._normalize_and_validate_features (core.py:1176-1196) and

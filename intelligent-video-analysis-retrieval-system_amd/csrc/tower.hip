@@ -22,7 +22,10 @@ int ivr_tower_create(ivr_ctx *ctx, const ivr_tower_desc *d, ivr_tower **out) {
     IVR_REQUIRE(d->tokens >= 1 && d->tokens <= 1024, "ivr_tower_create: tokens=%d", d->tokens);
     IVR_REQUIRE(d->out_dim >= 0 && d->out_dim % 16 == 0 && d->out_dim <= 2048, "ivr_tower_create: out_dim=%d", d->out_dim);
     IVR_REQUIRE(d->act == IVR_ACT_QUICK_GELU || d->act == IVR_ACT_GELU_ERF, "ivr_tower_create: act=%d", d->act);
-    IVR_REQUIRE(d->compute == IVR_COMPUTE_BF16 || d->compute == IVR_COMPUTE_F32, "ivr_tower_create: compute=%d", d->compute);
+    IVR_REQUIRE(d->compute == IVR_COMPUTE_BF16 || d->compute == IVR_COMPUTE_F32 || d->compute == IVR_COMPUTE_FP8,
+                "ivr_tower_create: compute=%d", d->compute);
+    IVR_REQUIRE(d->compute != IVR_COMPUTE_FP8 || (d->width % 128 == 0 && d->mlp % 128 == 0),
+                "ivr_tower_create: the fp8 mode needs width and mlp to be multiples of 128 (width=%d mlp=%d)", d->width, d->mlp);
     if (d->kind == IVR_KIND_VISION) {
         IVR_REQUIRE(d->patch >= 1 && d->image % d->patch == 0, "ivr_tower_create: patch=%d image=%d", d->patch, d->image);
         const int g = d->image / d->patch;
@@ -108,7 +111,7 @@ unsigned short host_bf16(float f) {
 
 // upload `count` floats either as f32 or converted to bf16 (GEMM operands in bf16 mode)
 int upload(ivr_tower *t, const std::string &name, const float *host, int64_t count, bool as_compute) {
-    const bool bf16 = as_compute && t->d.compute == IVR_COMPUTE_BF16;
+    const bool bf16 = as_compute && t->d.compute != IVR_COMPUTE_F32;
     TowerTensor tt;
     tt.count = count;
     tt.bytes_per = bf16 ? 2 : 4;
@@ -129,45 +132,105 @@ int upload(ivr_tower *t, const std::string &name, const float *host, int64_t cou
     return IVR_OK;
 }
 
+// float32 -> OCP e4m3 (bias 7, no infinity, max 448), round to nearest even, saturating
+unsigned char host_e4m3(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const unsigned char sign = (unsigned char)((u >> 24) & 0x80);
+    const float a = fabsf(f);
+    if (a != a) return (unsigned char)(sign | 0x7f);
+    if (a >= 448.f) return (unsigned char)(sign | 0x7e);
+    if (a < 0.015625f) return (unsigned char)(sign | (unsigned char)nearbyintf(a * 512.f));   // subnormals: multiples of 2^-9 (8 -> 2^-6)
+    int e;
+    const float m = frexpf(a, &e);                       // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1, mant = (int)nearbyintf((m * 2.f - 1.f) * 8.f);
+    if (mant == 8) {
+        mant = 0;
+        ++E;
+    }
+    if (E > 8 || (E == 8 && mant == 7)) return (unsigned char)(sign | 0x7e);
+    return (unsigned char)(sign | ((E + 7) << 3) | mant);
+}
+
+// fp8 mode: weight [N, K] -> e4m3 bytes with one scale per output row (absmax / 448), stored as `name` and `name`_s
+int upload_fp8(ivr_tower *t, const std::string &name, const float *host, int64_t N, int64_t K) {
+    std::vector<unsigned char> q((size_t)(N * K));
+    std::vector<float> sc((size_t)N);
+    for (int64_t n = 0; n < N; ++n) {
+        float amax = 0.f;
+        for (int64_t k = 0; k < K; ++k) amax = std::max(amax, fabsf(host[n * K + k]));
+        const float s = amax > 0.f ? amax / 448.f : 1.f, inv = 1.f / s;
+        sc[(size_t)n] = s;
+        for (int64_t k = 0; k < K; ++k) q[(size_t)(n * K + k)] = host_e4m3(host[n * K + k] * inv);
+    }
+    TowerTensor tt;
+    tt.count = N * K;
+    tt.bytes_per = 1;
+    IVR_HIP(hipMalloc(&tt.ptr, q.size()));
+    IVR_HIP(hipMemcpy(tt.ptr, q.data(), q.size(), hipMemcpyHostToDevice));
+    auto it = t->w.find(name);
+    if (it != t->w.end()) {
+        (void)hipFree(it->second.ptr);
+        t->w.erase(it);
+    }
+    t->w[name] = tt;
+    TowerTensor ts;
+    ts.count = N;
+    ts.bytes_per = 4;
+    IVR_HIP(hipMalloc(&ts.ptr, (size_t)N * 4));
+    IVR_HIP(hipMemcpy(ts.ptr, sc.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    t->w[name + "_s"] = ts;
+    return IVR_OK;
+}
+
 template <typename T>
 T *wptr(ivr_tower *t, const std::string &name) {
     auto it = t->w.find(name);
     return it == t->w.end() ? nullptr : reinterpret_cast<T *>(it->second.ptr);
 }
 
+// y = x W^T through the mode's GEMM: bf16 / f32 operands, or e4m3 operands with the weight's per-row scale
+int layer_gemm(ivr_tower *t, int epi, GemmArgs &g, const std::string &wname, hipStream_t s) {
+    g.W = wptr<void>(t, wname);
+    if (t->d.compute == IVR_COMPUTE_FP8) {
+        g.colscale = wptr<float>(t, wname + "_s");
+        return ivr_launch_gemm_fp8(epi, g, s);
+    }
+    return ivr_launch_gemm(t->d.compute == IVR_COMPUTE_F32, epi, g, s);
+}
+
 // one transformer stack over `rows` = n*T residual rows already in t->resid
 int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
     const ivr_tower_desc &d = t->d;
-    const bool f32 = d.compute == IVR_COMPUTE_F32;
+    const bool f32 = d.compute == IVR_COMPUTE_F32, fp8 = d.compute == IVR_COMPUTE_FP8;
+    const int act_kind = f32 ? OUT_F32 : fp8 ? OUT_FP8 : OUT_BF16;     // dtype of the GEMM A operands (LN / attention / MLP hidden)
     const int D = d.width, rows = n * T;
     int rc;
     for (int i = 0; i < d.layers; ++i) {
         const std::string p = "l" + std::to_string(i) + ".";
         if (t->debug_out && t->debug_layer == i)
             IVR_HIP(hipMemcpyAsync(t->debug_out, t->resid, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s));
-        rc = ivr_launch_layernorm(f32, t->resid, 1, nullptr, wptr<float>(t, p + "ln1_g"), wptr<float>(t, p + "ln1_b"), d.ln_eps,
+        rc = ivr_launch_layernorm(act_kind, t->resid, 1, nullptr, wptr<float>(t, p + "ln1_g"), wptr<float>(t, p + "ln1_b"), d.ln_eps,
                                   t->xn, rows, D, s);
         if (rc) return rc;
         GemmArgs g;
         g.A = t->xn;
         g.lda = D;
-        g.W = wptr<void>(t, p + "qkv_w");
         g.ldw = D;
         g.M = rows;
         g.N = 3 * D;
         g.K = D;
         g.bias = wptr<float>(t, p + "qkv_b");
-        g.out = t->qkv;
+        g.out = t->qkv;                  // bf16 in the fp8 mode too: the attention products stay on the bf16 MFMA
         g.ldo = 3 * D;
         g.tag = "gemm_qkv";
-        rc = ivr_launch_gemm(f32, EPI_STORE, g, s);
+        rc = layer_gemm(t, EPI_STORE, g, p + "qkv_w", s);
         if (rc) return rc;
-        rc = ivr_launch_attention(f32, t->qkv, t->att, n, T, D, d.heads, d.causal, s);
+        rc = ivr_launch_attention(f32, t->qkv, t->att, n, T, D, d.heads, d.causal, s, fp8);
         if (rc) return rc;
         g = GemmArgs();
         g.A = t->att;
         g.lda = D;
-        g.W = wptr<void>(t, p + "o_w");
         g.ldw = D;
         g.M = rows;
         g.N = D;
@@ -176,15 +239,14 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.resid = t->resid;
         g.ldr = D;
         g.tag = "gemm_attn_out";
-        rc = ivr_launch_gemm(f32, EPI_RESID, g, s);
+        rc = layer_gemm(t, EPI_RESID, g, p + "o_w", s);
         if (rc) return rc;
-        rc = ivr_launch_layernorm(f32, t->resid, 1, nullptr, wptr<float>(t, p + "ln2_g"), wptr<float>(t, p + "ln2_b"), d.ln_eps,
+        rc = ivr_launch_layernorm(act_kind, t->resid, 1, nullptr, wptr<float>(t, p + "ln2_g"), wptr<float>(t, p + "ln2_b"), d.ln_eps,
                                   t->xn, rows, D, s);
         if (rc) return rc;
         g = GemmArgs();
         g.A = t->xn;
         g.lda = D;
-        g.W = wptr<void>(t, p + "fc1_w");
         g.ldw = D;
         g.M = rows;
         g.N = d.mlp;
@@ -193,13 +255,13 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.out = t->hid;
         g.ldo = d.mlp;
         g.act = d.act;
+        g.out8 = fp8;
         g.tag = "gemm_fc1";
-        rc = ivr_launch_gemm(f32, EPI_STORE, g, s);
+        rc = layer_gemm(t, EPI_STORE, g, p + "fc1_w", s);
         if (rc) return rc;
         g = GemmArgs();
         g.A = t->hid;
         g.lda = d.mlp;
-        g.W = wptr<void>(t, p + "fc2_w");
         g.ldw = d.mlp;
         g.M = rows;
         g.N = D;
@@ -208,7 +270,7 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.resid = t->resid;
         g.ldr = D;
         g.tag = "gemm_fc2";
-        rc = ivr_launch_gemm(f32, EPI_RESID, g, s);
+        rc = layer_gemm(t, EPI_RESID, g, p + "fc2_w", s);
         if (rc) return rc;
     }
     if (t->debug_out && t->debug_layer == d.layers)
@@ -224,12 +286,12 @@ int run_pool(ivr_tower *t, int n, int T, const int *offs, int normalize, float *
     const int D = d.width;
     int rc;
     if (d.pool == IVR_POOL_LN_ALL_CLS) {
-        rc = ivr_launch_layernorm(true, t->resid, T, offs, wptr<float>(t, "post_ln_g"), wptr<float>(t, "post_ln_b"), d.ln_eps,
+        rc = ivr_launch_layernorm(OUT_F32, t->resid, T, offs, wptr<float>(t, "post_ln_g"), wptr<float>(t, "post_ln_b"), d.ln_eps,
                                   t->pooled_f32, n, D, s);
         if (rc) return rc;
         return ivr_launch_f_normalize(t->pooled_f32, out, n, D, normalize, s);
     }
-    rc = ivr_launch_layernorm(f32, t->resid, T, offs, wptr<float>(t, "post_ln_g"), wptr<float>(t, "post_ln_b"), d.ln_eps, t->pool, n,
+    rc = ivr_launch_layernorm(f32 ? OUT_F32 : OUT_BF16, t->resid, T, offs, wptr<float>(t, "post_ln_g"), wptr<float>(t, "post_ln_b"), d.ln_eps, t->pool, n,
                               D, s);
     if (rc) return rc;
     GemmArgs g;
@@ -305,11 +367,18 @@ int ivr_tower_finalize(ivr_tower *t, int max_batch) {
         for (int j = 0; j < D; ++j) qb[j] = H(p + "q_b")[j] * scale;
         memcpy(&qb[D], H(p + "k_b").data(), (size_t)D * 4);
         memcpy(&qb[2 * D], H(p + "v_b").data(), (size_t)D * 4);
-        if ((rc = upload(t, p + "qkv_w", qkv.data(), (int64_t)qkv.size(), true))) return rc;
+        if (d.compute == IVR_COMPUTE_FP8) {
+            if ((rc = upload_fp8(t, p + "qkv_w", qkv.data(), 3 * D, D))) return rc;
+            if ((rc = upload_fp8(t, p + "o_w", H(p + "o_w").data(), D, D))) return rc;
+            if ((rc = upload_fp8(t, p + "fc1_w", H(p + "fc1_w").data(), d.mlp, D))) return rc;
+            if ((rc = upload_fp8(t, p + "fc2_w", H(p + "fc2_w").data(), D, d.mlp))) return rc;
+        } else {
+            if ((rc = upload(t, p + "qkv_w", qkv.data(), (int64_t)qkv.size(), true))) return rc;
+            if ((rc = upload(t, p + "o_w", H(p + "o_w").data(), (int64_t)D * D, true))) return rc;
+            if ((rc = upload(t, p + "fc1_w", H(p + "fc1_w").data(), (int64_t)d.mlp * D, true))) return rc;
+            if ((rc = upload(t, p + "fc2_w", H(p + "fc2_w").data(), (int64_t)d.mlp * D, true))) return rc;
+        }
         if ((rc = upload(t, p + "qkv_b", qb.data(), 3 * D, false))) return rc;
-        if ((rc = upload(t, p + "o_w", H(p + "o_w").data(), (int64_t)D * D, true))) return rc;
-        if ((rc = upload(t, p + "fc1_w", H(p + "fc1_w").data(), (int64_t)d.mlp * D, true))) return rc;
-        if ((rc = upload(t, p + "fc2_w", H(p + "fc2_w").data(), (int64_t)d.mlp * D, true))) return rc;
         for (const char *n : {"ln1_g", "ln1_b", "ln2_g", "ln2_b", "o_b", "fc2_b"})
             if ((rc = upload(t, p + n, H(p + n).data(), D, false))) return rc;
         if ((rc = upload(t, p + "fc1_b", H(p + "fc1_b").data(), d.mlp, false))) return rc;
@@ -320,11 +389,12 @@ int ivr_tower_finalize(ivr_tower *t, int max_batch) {
     t->host.clear();
 
     // activation workspace, one allocation
-    const size_t es = d.compute == IVR_COMPUTE_F32 ? 4 : 2;
+    const size_t es = d.compute == IVR_COMPUTE_F32 ? 4 : 2;                       // qkv, pooled rows
+    const size_t ea = d.compute == IVR_COMPUTE_FP8 ? 1 : es;                      // GEMM A operands: LN out, attention out, MLP hidden
     const size_t rows = (size_t)max_batch * d.tokens;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t b_resid = al(rows * D * 4), b_xn = al(rows * D * es), b_qkv = al(rows * 3 * D * es), b_att = al(rows * D * es),
-                 b_hid = al(rows * d.mlp * es), b_pool = al((size_t)max_batch * D * es),
+    const size_t b_resid = al(rows * D * 4), b_xn = al(rows * D * ea), b_qkv = al(rows * 3 * D * es), b_att = al(rows * D * ea),
+                 b_hid = al(rows * d.mlp * ea), b_pool = al((size_t)max_batch * D * es),
                  b_pf = al((size_t)max_batch * std::max(D, d.out_dim) * 4), b_eos = al((size_t)max_batch * 4);
     t->ws_bytes = b_resid + b_xn + b_qkv + b_att + b_hid + b_pool + b_pf + b_eos;
     IVR_HIP(hipMalloc(&t->ws, t->ws_bytes));
@@ -382,7 +452,7 @@ int ivr_tower_encode_image(ivr_tower *t, const void *patches, int n, int normali
     rc = ivr_launch_gemm(f32, EPI_PATCH, g, s);
     if (rc) return rc;
     if (d.pre_ln) {
-        rc = ivr_launch_layernorm(true, t->resid, 1, nullptr, wptr<float>(t, "pre_ln_g"), wptr<float>(t, "pre_ln_b"), d.ln_eps, t->resid,
+        rc = ivr_launch_layernorm(OUT_F32, t->resid, 1, nullptr, wptr<float>(t, "pre_ln_g"), wptr<float>(t, "pre_ln_b"), d.ln_eps, t->resid,
                                   n * T, D, s);
         if (rc) return rc;
     }
@@ -434,6 +504,33 @@ int ivr_linear(ivr_ctx *ctx, int f32_mode, int epilogue, const void *x, const vo
     g.act = act;
     g.tag = "linear";
     return ivr_launch_gemm(f32_mode != 0, epilogue, g, (hipStream_t)stream);
+}
+
+int ivr_linear_fp8(ivr_ctx *ctx, int epilogue, const void *x, const void *w, const float *colscale, const float *bias, int M, int N, int K,
+                   int act, void *out, int out_fp8, float *resid, ivr_stream stream) {
+    IVR_REQUIRE(ctx && x && w, "ivr_linear_fp8: NULL argument");
+    IVR_REQUIRE(epilogue == EPI_STORE || epilogue == EPI_RESID, "ivr_linear_fp8: epilogue=%d", epilogue);
+    IVR_REQUIRE(M >= 0 && N >= 64 && K >= 128, "ivr_linear_fp8: M=%d N=%d K=%d", M, N, K);
+    IVR_REQUIRE(epilogue == EPI_RESID ? resid != nullptr : out != nullptr, "ivr_linear_fp8: NULL output");
+    IVR_HIP(hipSetDevice(ctx->device));
+    GemmArgs g;
+    g.A = x;
+    g.lda = K;
+    g.W = w;
+    g.ldw = K;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.bias = bias;
+    g.colscale = colscale;
+    g.out = out;
+    g.ldo = N;
+    g.out8 = out_fp8;
+    g.resid = resid;
+    g.ldr = N;
+    g.act = act;
+    g.tag = "linear_fp8";
+    return ivr_launch_gemm_fp8(epilogue, g, (hipStream_t)stream);
 }
 
 int ivr_tower_debug_hidden(ivr_tower *t, int layer, int n, float *out, ivr_stream) {

@@ -20,13 +20,18 @@ struct GemmArgs {
     int act = -1;                  // EPI_STORE: -1 none, else IVR_ACT_*
     const char *tag = nullptr;     // profiler name of this call site
     int group_m = 8;               // row panels per L2-resident group (tile order of gemm_kernel)
+    const float *colscale = nullptr;   // fp8 GEMM: per-output-column dequantisation scale [N] (NULL = 1)
+    int out8 = 0;                  // fp8 GEMM, EPI_STORE: write saturated e4m3 instead of bf16
     int wide_epi = 0;              // set by the launcher: 256 x 256 kernel may use the row-wide LDS-staged epilogue
 };
 
 int ivr_launch_gemm(bool f32, int epi, const GemmArgs &g, hipStream_t s);
-int ivr_launch_layernorm(bool out_f32, const float *x, int row_mul, const int *offs, const float *g, const float *b, float eps,
+int ivr_launch_gemm_fp8(int epi, const GemmArgs &g, hipStream_t s);   // A, W: e4m3 bytes; 256 x 256 kernel only
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_FP8 = 2 };
+int ivr_launch_layernorm(int out_kind, const float *x, int row_mul, const int *offs, const float *g, const float *b, float eps,
                          void *out, int rows, int D, hipStream_t s);
-int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int D, int heads, int causal, hipStream_t s);
+int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int D, int heads, int causal, hipStream_t s,
+                         bool out_fp8 = false);
 int ivr_launch_vision_cls(float *resid, const float *cls, const float *pos, int n, int T, int D, hipStream_t s);
 int ivr_launch_text_embed(float *resid, const int64_t *ids, const float *tok, const float *pos, int q, int T, int D, int vocab,
                           int eos, int *eos_pos, hipStream_t s);

@@ -50,6 +50,23 @@ struct El<unsigned short> {
         *reinterpret_cast<uint2 *>(p) = o;
     }
 };
+// four floats -> four OCP e4m3 bytes, saturated to +-448 (v_med3 first: the converter's overflow result is mode-dependent)
+__device__ __forceinline__ uint32_t ivr_pack_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
+    b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
+    d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+template <>
+struct El<unsigned char> {       // e4m3 activations of the fp8 mode
+    static __device__ __forceinline__ void store4(unsigned char *p, const float (&v)[4]) {
+        *reinterpret_cast<uint32_t *>(p) = ivr_pack_fp8x4(v[0], v[1], v[2], v[3]);
+    }
+};
 template <>
 struct El<float> {
     static constexpr int per16 = 4;
@@ -367,13 +384,50 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 // store tail is bound by the number of vector-memory instructions and the lines each one touches, not by bytes (s_memtime
 // stamps: 18.9k -> 6.3k cycles of a 55k-cycle qkv tile).  LDS images are XOR-swizzled by row: writes and reads are
 // conflict-free.
-template <typename T, int EPI, int ACT>
+template <typename T, int EPI, int ACT, bool SCALED = false, bool OUT8 = false>
 __device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4][8], unsigned char *wb, int row0, int col0, int lane) {
     const int r = lane & 15, gq = lane >> 4;
     float4 bv[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
         bv[nt] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + col0 + nt * 16 + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SCALED) {                 // fp8 GEMM: per-column dequantisation scale of the weight rows
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float4 sv = g.colscale ? *reinterpret_cast<const float4 *>(g.colscale + col0 + nt * 16 + 4 * gq) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                acc[nt][mt][0] *= sv.x;
+                acc[nt][mt][1] *= sv.y;
+                acc[nt][mt][2] *= sv.z;
+                acc[nt][mt][3] *= sv.w;
+            }
+        }
+    }
+    if (EPI == EPI_STORE && OUT8) {
+        // e4m3 output: 64-byte rows in LDS, 16-B chunk nt at position nt ^ ((row >> 1) & 3); read back 16 rows x 64 B per store
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 a = acc[nt][mt];
+                float v[4] = {a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w};
+                if (ACT >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = act_fn<true>(v[i], ACT);
+                }
+                *reinterpret_cast<uint32_t *>(wb + (mt * 16 + r) * 64 + ((nt ^ ((r >> 1) & 3)) << 4) + gq * 4) =
+                    ivr_pack_fp8x4(v[0], v[1], v[2], v[3]);
+            }
+        unsigned char *outp = reinterpret_cast<unsigned char *>(g.out) + col0 + (lane & 3) * 16;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int R = it * 16 + (lane >> 2);
+            const uint4 v = *reinterpret_cast<const uint4 *>(wb + R * 64 + (((lane & 3) ^ ((R >> 1) & 3)) << 4));
+            if (row0 + R < g.M) *reinterpret_cast<uint4 *>(outp + (int64_t)(row0 + R) * g.ldo) = v;
+        }
+        return;
+    }
     if (EPI == EPI_STORE) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
@@ -475,6 +529,7 @@ __device__ __forceinline__ void wait_vm_barrier() {
 // ---------------------------------------------------------------------------------------------
 constexpr int LBM = 256, LBN = 256, LX_BYTES = LBM * ROWB, LW_BYTES = LBN * ROWB, LSTAGE = LX_BYTES + LW_BYTES;
 constexpr int BIG_LDS = 2 * LSTAGE;   // 128 KiB
+constexpr int BIG8_LDS = BIG_LDS + 8 * 1024;   // + one dump slot per wave (fp8 kernel)
 
 template <typename T, int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
@@ -615,7 +670,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
 
     if (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_RESID) && g.wide_epi) {
         __builtin_amdgcn_s_barrier();                         // every wave has read its last fragments
-        wide_epilogue<T, EPI, ACT>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
+        if (n0 + wn * 64 < g.N)                               // N is a multiple of 64: a wave block is all in or all out
+            wide_epilogue<T, EPI, ACT>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
 #ifdef IVR_GEMM_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         IVR_STAMP(3)
@@ -697,6 +753,146 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     IVR_STAMP(3)
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp8 GEMM (IVR_COMPUTE_FP8, BASELINE config 5): the 256 x 256 kernel above with e4m3 operands and
+// v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), i.e. twice the K per MFMA at the same cycles per stage.
+//   * a stage is still 128 bytes of K per row = 128 e4m3 elements, the LDS images, swizzle and DMA are unchanged;
+//   * an MFMA wants 32 bytes of K per lane.  Lane group g takes chunks g and g+4 of the row (the two reads of the bf16
+//     kernel) rather than the contiguous pair 2g, 2g+1, which would be a 2-way bank conflict; A and B use the same
+//     permutation of K, so the contraction is unchanged;
+//   * one MFMA per (row tile, column tile) per stage needs BOTH halves of both fragments, so the pipeline is split by row
+//     tiles: G0 = row tiles 0-3, G1 = row tiles 4-7, both walking the column tiles in the outer loop.  X tiles 4-7 are read
+//     under G0, X tiles 0-3 of the next stage under G1, and the next stage's W[nt] right after G1 has issued its last MFMA
+//     on W[nt]; the wait + barrier sits between G0 and G1 as in the bf16 kernel.
+//   * epilogue: acc * colscale[n] + bias[n] through the row-wide LDS-staged path (bf16, e4m3 or f32 residual output).
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int ACT, bool OUT8>
+__global__ __launch_bounds__(512, 2) void gemm_big8_kernel(GemmArgs g) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
+    int tm, tn;
+    {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;
+        if (i >= lx * NT) return;
+        const int gm = g.group_m;
+        const int per = gm * NT, grp = i / per, within = i - grp * per;
+        const int gme = min(gm, lx - grp * gm);
+        tm = xcd + 8 * (grp * gm + within % gme);
+        tn = within / gme;
+    }
+    const int m0 = tm * LBM, n0 = tn * LBN;
+    const int KT = g.K / ROWB;                           // 128 e4m3 elements per stage
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    unsigned voffX[4], voffW[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (wave * 4 + j) + (lane >> 3), c = (lane & 7) ^ (lane >> 3);
+        voffX[j] = (unsigned)(r * g.lda) + c * 16;
+        voffW[j] = (unsigned)(r * g.ldw) + c * 16;
+    }
+    // The LDS-DMA is issued from inline asm: the compiler then sees no pending LDS write, so the fragment reads can be
+    // ordinary LDS loads (two ds_read_b128 land directly in the halves of an 8-register MFMA operand, and lgkmcnt is
+    // counted by the compiler) without the s_waitcnt vmcnt(0) it would put in front of them.  Ordering is explicit: every
+    // asm below clobbers memory, and the data is only read after the asm vmcnt(0) + barrier that follows its DMA.
+    const unsigned long long xb = (unsigned long long)g.A, wb8 = (unsigned long long)g.W;
+    const v4i rsX = {(int)(unsigned)xb, (int)((xb >> 32) & 0xffff), (int)((int64_t)g.M * g.lda), 0x00020000};
+    const v4i rsW = {(int)(unsigned)wb8, (int)((wb8 >> 32) & 0xffff), (int)((int64_t)g.N * g.ldw), 0x00020000};
+    const unsigned sx0 = (unsigned)m0 * (unsigned)g.lda, sw0 = (unsigned)n0 * (unsigned)g.ldw;
+    // `on` = false turns the piece into a no-op without a branch (zero-length descriptor: nothing is fetched, and the zeros
+    // it delivers go to a 1 KiB dump slot per wave behind the two stages), which keeps a whole K step in one basic block
+    // for the scheduler barriers below.
+    const unsigned dump = lds0 + BIG_LDS + wave * 1024;
+    auto piece = [&](int kt, int buf, int j, bool on) {
+        const unsigned base = lds0 + buf * LSTAGE + (wave * 4) * 1024, adv = (unsigned)kt * ROWB;
+        v4i rs = j < 4 ? rsX : rsW;
+        rs[2] = on ? rs[2] : 0;
+        const unsigned dst = on ? (j < 4 ? base + j * 1024 : base + LX_BYTES + (j - 4) * 1024) : dump;
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(j < 4 ? voffX[j] : voffW[j - 4]), "s"(rs),
+                     "s"((j < 4 ? sx0 : sw0) + adv)
+                     : "memory", "m0");
+    };
+    // fragment offsets: row (lane & 15) of a 16-row tile, 16-B chunks g and g+4 of the 128-byte row (swizzled)
+    unsigned fo[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fo[kk] = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+    const unsigned offX = (wm * 128) * ROWB, offW = LX_BYTES + (wn * 64) * ROWB;
+    auto frag = [&](unsigned base, int tile) -> v8i {
+        const v4i lo = *reinterpret_cast<const v4i *>(smem + base + fo[0] + tile * 2048);
+        const v4i hi = *reinterpret_cast<const v4i *>(smem + base + fo[1] + tile * 2048);
+        return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    f32x4 acc[4][8];   // [nt][mt]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v8i xf[8], wf[4];
+// four MFMAs of one column tile; the empty asm ties the group to the program order of the (volatile) DMA / barrier asm
+#define IVR_MMA8(NT, LO)                                                                                   \
+    _Pragma("unroll") for (int mt = LO; mt < LO + 4; ++mt)                                                 \
+        acc[NT][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[NT], xf[mt], acc[NT][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); \
+    asm volatile("" : "+v"(acc[NT][LO]), "+v"(acc[NT][LO + 1]), "+v"(acc[NT][LO + 2]), "+v"(acc[NT][LO + 3]));  \
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+    for (int j = 0; j < 8; ++j) piece(0, 0, j, true);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (KT > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) piece(1, 1, j, true);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xf[i] = frag(offX, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = frag(offW, i);
+    for (int kt = 0; kt < KT; ++kt) {
+        const unsigned boff = (kt & 1) * LSTAGE, noff = ((kt + 1) & 1) * LSTAGE;
+        const bool tail = kt >= 1 && kt + 1 < KT;
+        const bool more = kt + 2 < KT;
+        IVR_MMA8(0, 0)
+        piece(kt + 1, (kt + 1) & 1, 6, tail);
+        xf[4] = frag(boff + offX, 4);
+        xf[5] = frag(boff + offX, 5);
+        IVR_MMA8(1, 0)
+        piece(kt + 1, (kt + 1) & 1, 7, tail);
+        xf[6] = frag(boff + offX, 6);
+        xf[7] = frag(boff + offX, 7);
+        IVR_MMA8(2, 0)
+        IVR_MMA8(3, 0)
+        // every read of this stage has been issued and must have landed before the buffer is handed to the DMA.
+        // (The loads of the next stage's fragments are unconditional: in the last iteration they fetch stale bytes of the
+        // other buffer that nothing uses - a conditional 8-register update costs a register copy per lane per tile.)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = frag(noff + offX, i);
+        IVR_MMA8(0, 4)
+        piece(kt + 2, kt & 1, 0, more);
+        wf[0] = frag(noff + offW, 0);
+        piece(kt + 2, kt & 1, 4, more);
+        IVR_MMA8(1, 4)
+        piece(kt + 2, kt & 1, 1, more);
+        wf[1] = frag(noff + offW, 1);
+        piece(kt + 2, kt & 1, 5, more);
+        IVR_MMA8(2, 4)
+        piece(kt + 2, kt & 1, 2, more);
+        wf[2] = frag(noff + offW, 2);
+        IVR_MMA8(3, 4)
+        piece(kt + 2, kt & 1, 3, more);
+        wf[3] = frag(noff + offW, 3);
+    }
+#undef IVR_MMA8
+    __builtin_amdgcn_s_barrier();                             // every wave has read its last fragments
+    if (n0 + wn * 64 < g.N)
+        wide_epilogue<unsigned short, EPI, ACT, true, OUT8>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -993,8 +1189,8 @@ __device__ __forceinline__ float quad_sum(float x) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-template <int QC>
-__global__ __launch_bounds__(384, 3) void attention_head_kernel(const unsigned short *__restrict__ qkv, unsigned short *__restrict__ att,
+template <int QC, typename TOut>
+__global__ __launch_bounds__(384, 3) void attention_head_kernel(const unsigned short *__restrict__ qkv, TOut *__restrict__ att,
                                                                 int Tn, int D, int heads, int causal, int nsplit, int Tp) {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1163,11 +1359,11 @@ __global__ __launch_bounds__(384, 3) void attention_head_kernel(const unsigned s
         const float inv = __builtin_amdgcn_rcpf(quad_sum(l[qt]));
         const int q = 16 * (t0 + qt) + c;
         if (qt < nq && q < Tn) {
-            unsigned short *op = att + ((int64_t)img * Tn + q) * D + h * 64 + g * 4;
+            TOut *op = att + ((int64_t)img * Tn + q) * D + h * 64 + g * 4;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const float v[4] = {o[nt][qt][0] * inv, o[nt][qt][1] * inv, o[nt][qt][2] * inv, o[nt][qt][3] * inv};
-                El<unsigned short>::store4(op + nt * 16, v);
+                El<TOut>::store4(op + nt * 16, v);
             }
         }
     }
@@ -1187,8 +1383,9 @@ int gemm_mode() {
 // loop.  The K fragments of the head stay in registers (32) and the four 16-query tiles are processed one after the other
 // (S^T tile -> softmax -> P^T -> O^T tile -> store), which keeps the kernel at <= 128 VGPRs = 4 waves per SIMD: the kernel
 // is latency-bound (each wave touches 19 KB once), occupancy is what hides it.
+template <typename TOut>
 __global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsigned short *__restrict__ qkv,
-                                                                      unsigned short *__restrict__ att, int n, int Tn, int D, int heads,
+                                                                      TOut *__restrict__ att, int n, int Tn, int D, int heads,
                                                                       int causal) {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1269,7 +1466,7 @@ __global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsi
             pf[ks].w = ivr_pack_bf16x2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
         }
         const float inv = 1.0f / sum;
-        unsigned short *op = att + ((int64_t)img * Tn + qc) * D + h * 64 + g * 4;
+        TOut *op = att + ((int64_t)img * Tn + qc) * D + h * 64 + g * 4;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -1282,7 +1479,7 @@ __global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsi
             }
             if (q < Tn) {
                 const float v[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
-                El<unsigned short>::store4(op + nt * 16, v);
+                El<TOut>::store4(op + nt * 16, v);
             }
         }
     }
@@ -1311,12 +1508,12 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
         }
         const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
         ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 8);     // measured: narrow outputs want short groups
-        // the row-wide epilogue needs whole 64-column wave blocks and 16-byte aligned rows
+        // the row-wide epilogue needs whole 64-column wave blocks (N % 64 == 0) and 16-byte aligned rows
         const bool bias_ok = !g.bias || reinterpret_cast<uintptr_t>(g.bias) % 16 == 0;
         if (EPI == EPI_STORE)
-            ga.wide_epi = wide_env && bias_ok && g.N % LBN == 0 && g.ldo % 8 == 0 && reinterpret_cast<uintptr_t>(g.out) % 16 == 0;
+            ga.wide_epi = wide_env && bias_ok && g.N % 64 == 0 && g.ldo % 8 == 0 && reinterpret_cast<uintptr_t>(g.out) % 16 == 0;
         else if (EPI == EPI_RESID)
-            ga.wide_epi = wide_env && bias_ok && g.N % LBN == 0 && g.ldr % 4 == 0 && reinterpret_cast<uintptr_t>(g.resid) % 16 == 0;
+            ga.wide_epi = wide_env && bias_ok && g.N % 64 == 0 && g.ldr % 4 == 0 && reinterpret_cast<uintptr_t>(g.resid) % 16 == 0;
         const int grid = 8 * ((MT + 7) / 8) * NT;
         hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT>), dim3(grid), dim3(512), BIG_LDS, s, ga);
         IVR_LAUNCH_CHECK();
@@ -1363,14 +1560,66 @@ int ivr_launch_gemm(bool f32, int epi, const GemmArgs &g, hipStream_t s) {
     return f32 ? launch_gemm_e<float>(epi, g, s) : launch_gemm_e<unsigned short>(epi, g, s);
 }
 
-int ivr_launch_layernorm(bool out_f32, const float *x, int row_mul, const int *offs, const float *g, const float *b, float eps,
+namespace {
+template <int EPI, int ACT, bool OUT8>
+int launch_gemm8_t(const GemmArgs &g, hipStream_t s) {
+    IvrProf prof(g.tag ? g.tag : "gemm_fp8", s, 2.0 * g.M * g.N * g.K);
+    static bool attr_done = false;
+    if (!attr_done) {
+        IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big8_kernel<EPI, ACT, OUT8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, BIG8_LDS));
+        attr_done = true;
+    }
+    static int group_env = -1;
+    if (group_env < 0) {
+        const char *e = getenv("IVR_GEMM_GROUP_M");
+        group_env = e ? std::max(1, atoi(e)) : 0;
+    }
+    GemmArgs ga = g;
+    const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
+    ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 8);
+    ga.wide_epi = 1;
+    hipLaunchKernelGGL((gemm_big8_kernel<EPI, ACT, OUT8>), dim3(8 * ((MT + 7) / 8) * NT), dim3(512), BIG8_LDS, s, ga);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+}  // namespace
+
+int ivr_launch_gemm_fp8(int epi, const GemmArgs &g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return IVR_OK;
+    IVR_REQUIRE(epi == EPI_STORE || epi == EPI_RESID, "fp8 gemm: epilogue %d", epi);
+    IVR_REQUIRE(g.K >= 128 && g.K % 128 == 0 && g.lda % 16 == 0 && g.ldw % 16 == 0, "fp8 gemm: K=%d lda=%d ldw=%d (K %% 128, ld %% 16)", g.K,
+                g.lda, g.ldw);
+    IVR_REQUIRE(g.N % 64 == 0, "fp8 gemm: N=%d must be a multiple of 64", g.N);
+    IVR_REQUIRE((int64_t)g.M * g.lda < 0x7fffffff && (int64_t)g.N * g.ldw < 0x7fffffff, "fp8 gemm: operand beyond 2 GiB");
+    const auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    IVR_REQUIRE(al16(g.A) && al16(g.W) && al16(g.bias) && al16(g.colscale), "fp8 gemm: operands must be 16-byte aligned");
+    if (epi == EPI_RESID) {
+        IVR_REQUIRE(g.resid && g.ldr % 4 == 0 && al16(g.resid), "fp8 gemm: residual [M,%d] must be 16-byte aligned rows", g.ldr);
+        return launch_gemm8_t<EPI_RESID, -1, false>(g, s);
+    }
+    IVR_REQUIRE(g.out && al16(g.out) && g.ldo % (g.out8 ? 16 : 8) == 0, "fp8 gemm: output rows must be 16-byte aligned (ldo=%d)", g.ldo);
+    if (g.out8) {
+        if (g.act == IVR_ACT_QUICK_GELU) return launch_gemm8_t<EPI_STORE, IVR_ACT_QUICK_GELU, true>(g, s);
+        if (g.act == IVR_ACT_GELU_ERF) return launch_gemm8_t<EPI_STORE, IVR_ACT_GELU_ERF, true>(g, s);
+        return launch_gemm8_t<EPI_STORE, -1, true>(g, s);
+    }
+    if (g.act == IVR_ACT_QUICK_GELU) return launch_gemm8_t<EPI_STORE, IVR_ACT_QUICK_GELU, false>(g, s);
+    if (g.act == IVR_ACT_GELU_ERF) return launch_gemm8_t<EPI_STORE, IVR_ACT_GELU_ERF, false>(g, s);
+    return launch_gemm8_t<EPI_STORE, -1, false>(g, s);
+}
+
+int ivr_launch_layernorm(int out_kind, const float *x, int row_mul, const int *offs, const float *g, const float *b, float eps,
                          void *out, int rows, int D, hipStream_t s) {
     if (rows <= 0) return IVR_OK;
     IVR_REQUIRE(D % 4 == 0 && D <= 2048, "layernorm: D=%d", D);
     const unsigned grid = (unsigned)ivr_ceil_div(rows, 4);
-    IvrProf prof("layernorm", s, (double)rows * D * (4 + (out_f32 ? 4 : 2)));
-    if (out_f32)
+    IvrProf prof("layernorm", s, (double)rows * D * (4 + (out_kind == OUT_F32 ? 4 : out_kind == OUT_FP8 ? 1 : 2)));
+    if (out_kind == OUT_F32)
         hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, x, row_mul, offs, g, b, eps, (float *)out, rows, D);
+    else if (out_kind == OUT_FP8)
+        hipLaunchKernelGGL(layernorm_kernel<unsigned char>, dim3(grid), dim3(256), 0, s, x, row_mul, offs, g, b, eps,
+                           (unsigned char *)out, rows, D);
     else
         hipLaunchKernelGGL(layernorm_kernel<unsigned short>, dim3(grid), dim3(256), 0, s, x, row_mul, offs, g, b, eps,
                            (unsigned short *)out, rows, D);
@@ -1378,14 +1627,19 @@ int ivr_launch_layernorm(bool out_f32, const float *x, int row_mul, const int *o
     return IVR_OK;
 }
 
-int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int D, int heads, int causal, hipStream_t s) {
+int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int D, int heads, int causal, hipStream_t s, bool out_fp8) {
     if (n <= 0) return IVR_OK;
     // FLOP: QK^T and PV, 2*T*T*64 each per (image, head)
     IvrProf prof("attention", s, 4.0 * n * heads * (double)T * T * 64);
+    IVR_REQUIRE(!(f32 && out_fp8), "attention: e4m3 output only from the bf16 kernels");
     if (!f32 && T <= 64) {
         const int64_t items = (int64_t)n * heads;
-        hipLaunchKernelGGL(attention_mfma_short_kernel, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * VT_BYTES, s,
-                           (const unsigned short *)qkv, (unsigned short *)att, n, T, D, heads, causal);
+        if (out_fp8)
+            hipLaunchKernelGGL(attention_mfma_short_kernel<unsigned char>, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * VT_BYTES,
+                               s, (const unsigned short *)qkv, (unsigned char *)att, n, T, D, heads, causal);
+        else
+            hipLaunchKernelGGL(attention_mfma_short_kernel<unsigned short>, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * VT_BYTES,
+                               s, (const unsigned short *)qkv, (unsigned short *)att, n, T, D, heads, causal);
         IVR_LAUNCH_CHECK();
         return IVR_OK;
     }
@@ -1405,15 +1659,23 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
             const int lds = 2 * Tp * 128;
             static int attr_lds = 0;
             if (lds > attr_lds) {
-                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_head_kernel<QC>),
+                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_head_kernel<QC, unsigned short>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_head_kernel<QC, unsigned char>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 attr_lds = lds;
             }
-            hipLaunchKernelGGL(attention_head_kernel<QC>, dim3((unsigned)((int64_t)n * heads * nsplit)), dim3(64 * nw), lds, s,
-                               (const unsigned short *)qkv, (unsigned short *)att, T, D, heads, causal, nsplit, Tp);
+            const dim3 grid((unsigned)((int64_t)n * heads * nsplit)), block(64 * nw);
+            if (out_fp8)
+                hipLaunchKernelGGL((attention_head_kernel<QC, unsigned char>), grid, block, lds, s, (const unsigned short *)qkv,
+                                   (unsigned char *)att, T, D, heads, causal, nsplit, Tp);
+            else
+                hipLaunchKernelGGL((attention_head_kernel<QC, unsigned short>), grid, block, lds, s, (const unsigned short *)qkv,
+                                   (unsigned short *)att, T, D, heads, causal, nsplit, Tp);
             IVR_LAUNCH_CHECK();
             return IVR_OK;
         }
+        IVR_REQUIRE(!out_fp8, "attention: T=%d too long for the e4m3-output kernels", T);
         const int nqb = (T + 63) / 64;
         const int64_t items = (int64_t)n * heads * nqb;
         hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * VT_BYTES, s,

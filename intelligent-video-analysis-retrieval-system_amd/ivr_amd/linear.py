@@ -31,3 +31,33 @@ def linear(x, w, bias=None, act=-1, epilogue=EPI_STORE, resid=None):
                                   C.c_void_p(resid.data_ptr()) if resid is not None else None, _ffi.stream_ptr()),
                    "ivr_linear")
     return resid if epilogue == EPI_RESID else out
+
+
+def quantize_rows_e4m3(w):
+    """float32 [N,K] -> (e4m3 bytes as uint8 [N,K], float32 scale [N]) with one scale per row (absmax / 448): the weight
+    format of the fp8 tower mode, restated with torch's float8_e4m3fn conversion (round to nearest even, saturating)."""
+    amax = w.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax)).to(torch.float32)
+    q = (w / scale[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+def linear_fp8(x8, w8, colscale=None, bias=None, act=-1, epilogue=EPI_STORE, out_fp8=False, resid=None):
+    """x8 [M,K], w8 [N,K]: e4m3 bytes (uint8 or float8_e4m3fn CUDA tensors); y = (x8 w8^T) * colscale + bias."""
+    lib = _ffi.load()
+    x8, w8 = x8.contiguous(), w8.contiguous()
+    M, K = x8.shape
+    N = w8.shape[0]
+    out = None
+    if epilogue == EPI_STORE:
+        out = torch.empty((M, N), dtype=torch.uint8 if out_fp8 else torch.bfloat16, device=x8.device)
+    elif resid is None or resid.dtype != torch.float32 or tuple(resid.shape) != (M, N):
+        raise ValueError("EPI_RESID needs a float32 [M,N] residual tensor")
+    ptr = lambda a: C.c_void_p(a.data_ptr()) if a is not None else None   # noqa: E731
+    with torch.cuda.device(x8.device):
+        _ffi.check(lib.ivr_linear_fp8(_ffi.context(x8.device.index), int(epilogue), ptr(x8), ptr(w8), ptr(colscale), ptr(bias),
+                                      M, N, K, int(act), ptr(out), int(bool(out_fp8)), ptr(resid), _ffi.stream_ptr()),
+                   "ivr_linear_fp8")
+    if epilogue == EPI_RESID:
+        return resid
+    return out.view(torch.float8_e4m3fn) if out_fp8 else out

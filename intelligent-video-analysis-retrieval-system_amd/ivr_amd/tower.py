@@ -4,7 +4,8 @@ Stands in for the HuggingFace modules the reference calls at `core.py:1619`
 (`CLIPModel.get_image_features`), `core.py:1541` (`get_text_features`) and
 `video_frame_filter.py:31` (`ViTModel`).  Weights are the float32 master dict of
 `ivr_amd.weights` (synthetic or converted from an HF state dict); GEMM operands are
-cast to bf16 at upload unless `compute="f32"` (verification mode).
+cast to bf16 at upload unless `compute="f32"` (verification mode); `compute="fp8"` (BASELINE config 5) quantises the
+four linear layers of every block to e4m3 with one scale per output channel.
 """
 import ctypes as C
 
@@ -23,12 +24,13 @@ class Tower:
         self.compute = compute
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
         self.max_batch = int(max_batch)
-        self.act_dtype = torch.bfloat16 if compute == "bf16" else torch.float32
+        # patch-major pixels stay bf16 in the fp8 mode (only the four GEMMs of every block run on the fp8 MFMA)
+        self.act_dtype = torch.float32 if compute == "f32" else torch.bfloat16
         d = _ffi.TowerDesc(kind=0 if cfg.kind == "vision" else 1, width=cfg.width, layers=cfg.layers, heads=cfg.heads,
                            mlp=cfg.mlp, tokens=cfg.tokens, out_dim=cfg.out_dim, act=cfg.act, pool=cfg.pool,
                            image=cfg.image, patch=cfg.patch, pre_ln=int(cfg.pre_ln), patch_bias=int(cfg.patch_bias),
                            vocab=cfg.vocab, eos_id=cfg.eos_id, causal=int(cfg.causal),
-                           compute={"bf16": 0, "f32": 1}[compute], ln_eps=cfg.ln_eps)
+                           compute={"bf16": 0, "f32": 1, "fp8": 2}[compute], ln_eps=cfg.ln_eps)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _ffi.check(self._lib.ivr_tower_create(_ffi.context(self.device.index), C.byref(d), C.byref(h)),
