@@ -34,7 +34,7 @@ MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
 
 def cpu_baseline(cfg, weights, frames_u8, index_rows, queries, k, budget_s=20.0):
     """The oracle (a port: the reference's own Python cannot travel) timed on this box's host
-    cores on a bounded sample of the same workload: fp32 ViT-B/32 in batches of 32 (core.py:1558) and the exact
+    cores on a bounded sample of the same workload: the fp32 tower in batches of 32 (core.py:1558) and the exact
     inner-product top-k over a slice of the index."""
     from oracle import preprocess_ref as P
     from oracle import search_ref as S
@@ -62,7 +62,7 @@ def cpu_baseline(cfg, weights, frames_u8, index_rows, queries, k, budget_s=20.0)
             break
     t_search = (time.perf_counter() - t1) / reps
     return {"value": done / t_embed, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{done} frames of 224x224 through the fp32 oracle ViT-B/32 in batches of 32 "
+            "sample": f"{done} frames of 224x224 through the fp32 oracle {cfg.name} in batches of 32 "
                       f"({t_embed:.1f} s); exact IP top-{k} of {len(queries)} queries over {len(index_rows)} x "
                       f"{index_rows.shape[1]} rows, {reps} repeats",
             "pairs_per_s": len(index_rows) * len(queries) / t_search, "threads": torch.get_num_threads(), "emb_dim": int(emb.shape[1])}
@@ -79,6 +79,10 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=1, help="split each step's frames over this many HIP streams / towers")
+    # the defaults are BASELINE.json configs[1] (the metric's configuration); the two flags below select the
+    # configs[4]-shaped variant (ViT-L/14, fp8 GEMMs, 768-d rows) as an additional measurement, never the headline
+    ap.add_argument("--tower", choices=("b32", "l14"), default="b32")
+    ap.add_argument("--compute", choices=("bf16", "fp8"), default="bf16")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,40 +115,43 @@ def main():
     from ivr_amd.tower import Tower
     from ivr_amd.weights import make_weights
 
-    cfg = C.CLIP_VIT_B32
+    cfg = C.CLIP_VIT_B32 if args.tower == "b32" else C.CLIP_VIT_L14
+    headline = args.tower == "b32" and args.compute == "bf16"
+    d_emb, G2 = cfg.embed_dim, cfg.tokens - 1
+    kpad = (3 * cfg.patch * cfg.patch + 63) // 64 * 64
     B, N, Q, k = args.frames_per_step, args.index_rows, args.queries, args.k
     weights = make_weights(cfg, 12)
     L = max(1, args.lanes)
     assert B % L == 0
-    towers = [Tower(cfg, weights, max_batch=B // L, compute="bf16", device=local_rank) for _ in range(L)]
+    towers = [Tower(cfg, weights, max_batch=B // L, compute=args.compute, device=local_rank) for _ in range(L)]
     tower = towers[0]
     lanes = [torch.cuda.Stream(device=dev) for _ in range(L)] if L > 1 else [None]
 
     # synthetic inputs, generated on the device (a 100k-frame host array would be 15 GB)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     frame_tiles = [torch.randint(0, 256, (B, 224, 224, 3), generator=g, device=dev, dtype=torch.uint8) for _ in range(2)]
-    index = FlatIPIndex(512, capacity=N, device=local_rank)
+    index = FlatIPIndex(d_emb, capacity=N, device=local_rank)
     gi = torch.Generator(device=dev).manual_seed(5678 + rank)
     for i in range(0, N, 250_000):
-        rows = torch.randn((min(250_000, N - i), 512), generator=gi, device=dev, dtype=torch.float32)
+        rows = torch.randn((min(250_000, N - i), d_emb), generator=gi, device=dev, dtype=torch.float32)
         index.add(rows, normalize=True)
         del rows
-    queries = torch.from_numpy(np.random.default_rng(91011).standard_normal((Q, 512), dtype=np.float32)).to(dev)
+    queries = torch.from_numpy(np.random.default_rng(91011).standard_normal((Q, d_emb), dtype=np.float32)).to(dev)
     index.reserve_search(Q, k)
-    sharded = ShardedIndex(index, 512, merge="device")
+    sharded = ShardedIndex(index, d_emb, merge="device")
     sharded.sync_counts()
 
-    patches = torch.empty((B * 49, 3072), dtype=torch.bfloat16, device=dev)
-    emb = torch.empty((B, 512), dtype=torch.float32, device=dev)
+    patches = torch.empty((B * G2, kpad), dtype=torch.bfloat16, device=dev)
+    emb = torch.empty((B, d_emb), dtype=torch.float32, device=dev)
     ring = {"pos": 0}
     ev_s0, ev_s1 = [], []
 
     def embed(lane, i, pos):
         b = B // L
         fr = frame_tiles[i & 1][lane * b:(lane + 1) * b]
-        pt = patches[lane * b * 49:(lane + 1) * b * 49]
+        pt = patches[lane * b * G2:(lane + 1) * b * G2]
         em = emb[lane * b:(lane + 1) * b]
-        preprocess_frames(fr, "identity", C.CLIP_MEAN, C.CLIP_STD, size=224, patch=32, out=pt)
+        preprocess_frames(fr, "identity", C.CLIP_MEAN, C.CLIP_STD, size=224, patch=cfg.patch, out=pt)
         towers[lane].encode_patches(pt, b, normalize=True, out=em)
         index.write_device(pos + lane * b, em)          # rows are already L2-normalised by the tower epilogue
 
@@ -204,7 +211,7 @@ def main():
                 pmc = json.load(f)
         except OSError:
             pass
-        pmc_ok = B == pmc.get("_frames_per_step", -1) and N == 1_000_000
+        pmc_ok = headline and B == pmc.get("_frames_per_step", -1) and N == 1_000_000
 
         def traffic(*kernels):
             if not pmc_ok or not kernels or not all(k in pmc for k in kernels):
@@ -216,6 +223,7 @@ def main():
         gemm_ms = sum(v["ms"] for v in gemm.values())
         gemm_launches = sum(v["launches"] for v in gemm.values())
         gemm_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms else 0.0
+        mfma_peak = MFMA_BF16_PEAK_TF if args.compute == "bf16" else 2 * MFMA_BF16_PEAK_TF      # dense fp8 = 2 x dense bf16
 
         def hbm(name):
             v = prof.get(name)
@@ -230,15 +238,18 @@ def main():
             "metric": "frames/s embedded (+ query-vs-index cosine pairs/s; top-10 recall vs CPU ref)",
             "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ViT-B/32 bf16 random-init embed of 224x224 RGB frames + 1M-row x 512-d "
-                                   "fp32 index cosine top-10 (per GPU)",
+            "dtype": args.compute, "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[1]: ViT-B/32 bf16 random-init embed of 224x224 RGB frames + 1M-row x 512-d "
+                                    "fp32 index cosine top-10 (per GPU)") if headline else
+                                   (f"NOT the headline configuration: {cfg.name} {args.compute} random-init embed of 224x224 RGB frames + "
+                                    f"{N}-row x {d_emb}-d fp32 index cosine top-{k} (per GPU)"),
                        "frames_per_step_per_gpu": B, "frames_total": frames_total, "index_rows_per_gpu": N, "queries": Q, "k": k,
                        "parallelism": f"{world} x (frames + index rows sharded per GPU); one all-gather of (score,id) + merge"},
             "pairs_per_s": N * world * Q / (search_ms * 1e-3), "search_ms_per_step": search_ms,
-            "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TF,
+            "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": gemm_tf / mfma_peak,
                          "traffic": traffic(*[k for k in pmc if k.startswith(("gemm_big_kernel<bf16", "gemm_kernel<bf16"))]),
-                         "kernel": "gemm_big_kernel<bf16> / gemm_kernel<bf16> (all tower GEMM launches of the timed region)",
+                         "kernel": ("gemm_big_kernel<bf16> / gemm_kernel<bf16>" if args.compute == "bf16" else "gemm_big8_kernel (e4m3) + the bf16 patch / projection GEMMs")
+                                   + " (all tower GEMM launches of the timed region)",
                          "avg_launch_ms": gemm_ms / max(1, gemm_launches), "launches": int(gemm_launches),
                          "flop_per_launch": gemm_flop / max(1, gemm_launches),
                          "by_call_site": {n: {"TFLOP/s": v["work"] / (v["ms"] * 1e-3) / 1e12, "ms": v["ms"] / v["launches"]}
