@@ -1369,14 +1369,16 @@ __global__ __launch_bounds__(384, 3) void attention_head_kernel(const unsigned s
     }
 }
 
-// kernel choice, overridable for A/B runs: IVR_GEMM=0 the 128 x 128 kernel, 4 the 256 x 256 kernel; default by problem size
+// kernel choice, overridable for A/B runs and so that the parity tests can drive every kernel with every shape:
+// IVR_GEMM=0 the 128 x 128 kernel, 4 the 256 x 256 kernel; default by problem size.  Read on every launch (a getenv is
+// ~100 ns next to a multi-microsecond launch) so a test can flip it inside one process.
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
 int gemm_mode() {
-    static int v = -2;
-    if (v == -2) {
-        const char *e = getenv("IVR_GEMM");
-        v = (e && (e[0] == '0' || e[0] == '4')) ? e[0] - '0' : -1;
-    }
-    return v;
+    const int v = env_int("IVR_GEMM", -1);
+    return v == 0 || v == 4 ? v : -1;
 }
 
 // Short-sequence variant (T <= 64: CLIP ViT-B/32 has T = 50): one key block, so no online-softmax state has to survive a
@@ -1491,13 +1493,7 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     int mode = gemm_mode();
     // default (-1): the 256 x 256 kernel once it fills the chip, the 128 x 128 kernel for small problems
     if (mode < 0) mode = ((g.M + LBM - 1) / LBM) * ((g.N + LBN - 1) / LBN) >= 192 ? 4 : 0;
-    static int group_env = -1, wide_env = -1;
-    if (group_env < 0) {
-        const char *e = getenv("IVR_GEMM_GROUP_M");
-        group_env = e ? std::max(1, atoi(e)) : 0;
-        e = getenv("IVR_GEMM_WIDE_EPI");
-        wide_env = e ? atoi(e) != 0 : 1;
-    }
+    const int group_env = std::max(0, env_int("IVR_GEMM_GROUP_M", 0)), wide_env = env_int("IVR_GEMM_WIDE_EPI", 1);
     GemmArgs ga = g;
     if (mode == 4) {
         static bool attr_done = false;
@@ -1570,11 +1566,7 @@ int launch_gemm8_t(const GemmArgs &g, hipStream_t s) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, BIG8_LDS));
         attr_done = true;
     }
-    static int group_env = -1;
-    if (group_env < 0) {
-        const char *e = getenv("IVR_GEMM_GROUP_M");
-        group_env = e ? std::max(1, atoi(e)) : 0;
-    }
+    const int group_env = std::max(0, env_int("IVR_GEMM_GROUP_M", 0));
     GemmArgs ga = g;
     const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
     ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 8);
@@ -1645,11 +1637,7 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
     }
     if (!f32) {
         const int Tp = (int)ivr_round_up(T, 32);
-        static int head_env = -1;
-        if (head_env < 0) {
-            const char *e = getenv("IVR_ATTN_HEAD");
-            head_env = e ? atoi(e) : 1;
-        }
+        const int head_env = env_int("IVR_ATTN_HEAD", 1);     // 0: force the generic flash kernel (A/B, tests)
         if (head_env && 2 * Tp * 128 <= 160 * 1024 && (int64_t)T * 3 * D * 2 < 0x7fffffff) {
             // head-resident kernel: K and V of a head in LDS, QC query tiles of 16 per wave, at most 6 waves per workgroup
             constexpr int QC = 3;

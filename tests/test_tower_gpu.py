@@ -74,6 +74,24 @@ def test_vision_bf16_within_cosine_tolerance(cfg, n, golden):
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-5     # F.normalize applied
 
 
+@pytest.mark.parametrize("grid,patch,head_kernel", [(8, 4, 1), (10, 8, 1), (14, 8, 1), (16, 4, 1), (24, 4, 1), (28, 4, 1), (16, 4, 0)])
+def test_attention_sequence_lengths(grid, patch, head_kernel, monkeypatch):
+    """T = grid^2 + 1 tokens: 65 (first length past the one-block kernel), 101, 197 (DINO), 257 (ViT-L/14), 577 (ViT-L/14@336:
+    query split over 3 workgroups, 148 KB of LDS), 785 (past the LDS limit: generic flash kernel), and 257 again with the
+    head-resident kernel switched off.  A two-layer width-128 tower on small patches, bf16 vs the float32 oracle."""
+    from ivr_amd.config import TowerConfig
+    from ivr_amd.tower import Tower
+    monkeypatch.setenv("IVR_ATTN_HEAD", str(head_kernel))
+    cfg = TowerConfig(f"tiny-g{grid}", "vision", 128, 2, 2, 256, grid * grid + 1, 64, image=patch * grid, patch=patch)
+    w = make_weights(cfg, 21)
+    frames = synth_frames(77, 3, cfg.image, cfg.image)
+    out = Tower(cfg, w, max_batch=3).encode_frames(frames, "identity", C.CLIP_MEAN, C.CLIP_STD).cpu().numpy()
+    ref = np.asarray(V.vision_forward(cfg, w, P.preprocess(frames, "identity", C.CLIP_MEAN, C.CLIP_STD, size=cfg.image)))
+    cos = _cos(out, ref)
+    print(f"T={cfg.tokens} head_kernel={head_kernel} min cos={cos.min():.6f}")
+    assert cos.min() > 1 - 1e-4
+
+
 def test_batching_is_row_independent():
     """Ragged batch sizes and max_batch chunking do not change any row (bit-exact)."""
     cfg = C.CLIP_VIT_B32
