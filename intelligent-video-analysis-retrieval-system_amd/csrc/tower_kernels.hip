@@ -1386,7 +1386,7 @@ int gemm_mode() {
 // (S^T tile -> softmax -> P^T -> O^T tile -> store), which keeps the kernel at <= 128 VGPRs = 4 waves per SIMD: the kernel
 // is latency-bound (each wave touches 19 KB once), occupancy is what hides it.
 template <typename TOut>
-__global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsigned short *__restrict__ qkv,
+__global__ __launch_bounds__(256, 5) void attention_mfma_short_kernel(const unsigned short *__restrict__ qkv,
                                                                       TOut *__restrict__ att, int n, int Tn, int D, int heads,
                                                                       int causal) {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsi
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
     if (item >= (int64_t)n * heads) return;                 // waves are independent: no workgroup barrier below
     const int h = (int)(item % heads), img = (int)(item / heads);
-    unsigned char *vt = smem + wave * VT_BYTES;
+    unsigned char *vt = smem + wave * 8192;                 // 64 keys x 128 B of V per wave
     const int g = lane >> 4, c = lane & 15;
     const int64_t rs = 3 * (int64_t)D;
     const unsigned short *base = qkv + (int64_t)img * Tn * rs + h * 64;
@@ -1408,21 +1408,24 @@ __global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsi
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) kf[ks][kt] = *reinterpret_cast<const uint4 *>(base + D + key * rs + ks * 32 + g * 8);
     }
-    // V^T -> LDS: lane owns key `lane`, scatters its 64 dh values down a column
+    // V -> LDS row-major (lane owns key `lane`: eight 16-B stores); the V^T fragments are read back with the transposing
+    // ds_read_b64_tr_b16.  32-B segment s of a row sits at position s ^ ((row >> 1) & 3) (conflict-free transposed reads).
     {
         const int key = min(lane, Tn - 1);
         const uint4 *vp = reinterpret_cast<const uint4 *>(base + 2 * D + key * rs);
+        unsigned char *vrow = vt + lane * 128;
+        const int xr = (lane >> 1) & 3;
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            const uint4 v = vp[ch];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<unsigned short *>(vt + (ch * 8 + 2 * i) * VT_STRIDE + lane * 2) = (unsigned short)(w[i] & 0xffffu);
-                *reinterpret_cast<unsigned short *>(vt + (ch * 8 + 2 * i + 1) * VT_STRIDE + lane * 2) = (unsigned short)(w[i] >> 16);
-            }
-        }
+        for (int ch = 0; ch < 8; ++ch) *reinterpret_cast<uint4 *>(vrow + ((((ch >> 1) ^ xr) << 5) | ((ch & 1) << 4))) = vp[ch];
     }
+    unsigned offV[4];
+    {
+        const int vr = 4 * g + (c >> 2), xr = (2 * g + (c >> 3)) & 3;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) offV[nt] = (unsigned)(size_t)vt + vr * 128 + ((nt ^ xr) << 5) + (c & 3) * 8;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own V rows are in LDS before any transposed read
+    constexpr float L2E = 1.4426950408889634f;
     const int nqt = (Tn + 15) >> 4;
 #pragma unroll 1
     for (int qt = 0; qt < nqt; ++qt) {
@@ -1446,19 +1449,18 @@ __global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsi
             }
             s[kt] = acc;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = quad_max(mx);                    // finite: key 0 is visible to every query
+        const float mb = -mx * L2E;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = (s[kt][r] == -INFINITY) ? 0.f : __expf(s[kt][r] - mx);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], L2E, mb));      // masked (-inf) -> 0
                 s[kt][r] = p;
                 sum += p;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = quad_sum(sum);
         uint4 pf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1467,15 +1469,22 @@ __global__ __launch_bounds__(256, 4) void attention_mfma_short_kernel(const unsi
             pf[ks].z = ivr_pack_bf16x2(s[2 * ks + 1][0], s[2 * ks + 1][1]);
             pf[ks].w = ivr_pack_bf16x2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
         }
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         TOut *op = att + ((int64_t)img * Tn + qc) * D + h * 64 + g * 4;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const unsigned char *row = vt + (nt * 16 + c) * VT_STRIDE + ks * 64 + g * 8;
-                const uint2 lo = *reinterpret_cast<const uint2 *>(row), hi = *reinterpret_cast<const uint2 *>(row + 32);
+                uint2 lo, hi;
+                if (ks == 0)
+                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(lo), "=&v"(hi)
+                                 : "v"(offV[nt]));
+                else
+                    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:4096\n\tds_read_b64_tr_b16 %1, %2 offset:6144\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(lo), "=&v"(hi)
+                                 : "v"(offV[nt]));
                 const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[ks]), o, 0, 0, 0);
             }
@@ -1627,10 +1636,10 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
     if (!f32 && T <= 64) {
         const int64_t items = (int64_t)n * heads;
         if (out_fp8)
-            hipLaunchKernelGGL(attention_mfma_short_kernel<unsigned char>, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * VT_BYTES,
+            hipLaunchKernelGGL(attention_mfma_short_kernel<unsigned char>, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * 8192,
                                s, (const unsigned short *)qkv, (unsigned char *)att, n, T, D, heads, causal);
         else
-            hipLaunchKernelGGL(attention_mfma_short_kernel<unsigned short>, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * VT_BYTES,
+            hipLaunchKernelGGL(attention_mfma_short_kernel<unsigned short>, dim3((unsigned)ivr_ceil_div(items, 4)), dim3(256), 4 * 8192,
                                s, (const unsigned short *)qkv, (unsigned short *)att, n, T, D, heads, causal);
         IVR_LAUNCH_CHECK();
         return IVR_OK;
