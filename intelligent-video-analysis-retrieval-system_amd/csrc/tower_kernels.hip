@@ -528,7 +528,8 @@ __device__ __forceinline__ void wait_vm_barrier() {
 //     (2566 cycles per stage, 2048 = MFMA-bound), epilogue 6.7k cycles.
 // ---------------------------------------------------------------------------------------------
 constexpr int LBM = 256, LBN = 256, LX_BYTES = LBM * ROWB, LW_BYTES = LBN * ROWB, LSTAGE = LX_BYTES + LW_BYTES;
-constexpr int BIG_LDS = 2 * LSTAGE;   // 128 KiB
+constexpr int BIG_LDS = 2 * LSTAGE;   // 128 KiB (fp8 kernel: two whole stages)
+constexpr int DEEP_LDS = 3 * LX_BYTES + 2 * LW_BYTES;   // 160 KiB (bf16 / f32 kernel: three X slots, two W slots)
 constexpr int BIG8_LDS = BIG_LDS + 8 * 1024;   // + one dump slot per wave (fp8 kernel)
 
 template <typename T, int EPI, int ACT>
@@ -566,23 +567,27 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.A), 0, (int)((int64_t)g.M * g.lda * sizeof(T)), 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * sizeof(T)), 0x00020000);
     const unsigned sx0 = (unsigned)m0 * (unsigned)g.lda * (unsigned)sizeof(T), sw0 = (unsigned)n0 * (unsigned)g.ldw * (unsigned)sizeof(T);
-    auto stage = [&](int kt, int buf) {
-        unsigned char *base = smem + buf * LSTAGE + (wave * 4) * 1024;
+    // LDS: three X slots (the activation operand is usually HBM-fed: its DMA runs TWO stages ahead) and two W slots (the
+    // weight panel is L2 / Infinity-Cache resident: one stage ahead), 3 x 32 + 2 x 32 = 160 KiB.
+    // s_memtime stamps of the two-slot version: per stage the waves waited ~1000 cycles for the X DMA on the fc2 / attn-out
+    // shapes (A read once from HBM by 3 column tiles) against ~150 on qkv / fc1 (A panel shared by 9 - 12 tiles through L2).
+    constexpr int WBASE = 3 * LX_BYTES;
+    auto piece = [&](int kt, int xs, int j) {          // one 1 KiB DMA piece of stage kt: j < 4 X (slot xs), else W (slot kt & 1)
         const unsigned adv = (unsigned)kt * ROWB;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + j * 1024), 16, voffX[j],
-                                                     sx0 + adv, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + LX_BYTES + j * 1024), 16,
-                                                     voffW[j], sw0 + adv, 0, 0);
-        }
+        if (j < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(smem + xs * LX_BYTES + (wave * 4 + j) * 1024),
+                                                     16, voffX[j], sx0 + adv, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsW, (__attribute__((address_space(3))) void *)(smem + WBASE + (kt & 1) * LW_BYTES + (wave * 4 + j - 4) * 1024), 16,
+                voffW[j - 4], sw0 + adv, 0, 0);
     };
     unsigned foX[2], foW[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const unsigned f = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
         foX[kk] = lds0 + (wm * 128) * ROWB + f;
-        foW[kk] = lds0 + LX_BYTES + (wn * 64) * ROWB + f;
+        foW[kk] = lds0 + WBASE + (wn * 64) * ROWB + f;
     }
 
     f32x4 acc[4][8];   // [nt][mt]
@@ -591,16 +596,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto piece = [&](int kt, int buf, int j) {                 // one 1 KiB DMA piece of a stage: j < 4 X, else W
-        unsigned char *base = smem + buf * LSTAGE + (wave * 4) * 1024;
-        const unsigned adv = (unsigned)kt * ROWB;
-        if (j < 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(base + j * 1024), 16, voffX[j],
-                                                     sx0 + adv, 0, 0);
-        else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(base + LX_BYTES + (j - 4) * 1024),
-                                                     16, voffW[j - 4], sw0 + adv, 0, 0);
-    };
 #define IVR_ROW(XF, WF, MT)                                                                                \
     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) mma_chunk<T>(WF[nt], XF[MT], acc[nt][MT]);            \
     __builtin_amdgcn_sched_barrier(0);
@@ -615,25 +610,38 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
 
     u32x4 xa0[8], wa0[4], xa1[8], wa1[4];
     u32x4 *x0lo = xa0, *x0hi = xa0 + 4, *x1lo = xa1, *x1hi = xa1 + 4;
-    stage(0, 0);
+    // prologue: stage 0 whole, then X(1), W(1), X(2) in that order (the order the counted waits below rely on)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) piece(0, 0, j);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     IVR_STAMP(1)
-    if (KT > 1) stage(1, 1);
+    if (KT > 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) piece(1, 1, j);
+    }
+    if (KT > 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) piece(2, 2, j);
+    }
     IVR_RD4(wa0, foW[0], 0)
     IVR_RD4(x0lo, foX[0], 0)
     IVR_RD4(x0hi, foX[0], 8192)
+    int xs = 0;                                         // X slot of stage kt = kt % 3
     for (int kt = 0; kt < KT; ++kt) {
-        const unsigned boff = (kt & 1) * LSTAGE, noff = ((kt + 1) & 1) * LSTAGE;
-        const bool tail = kt >= 1 && kt + 1 < KT;       // last two pieces of stage kt+1 (the first stage-1 DMA went out whole)
-        const bool more = kt + 2 < KT, next = kt + 1 < KT;
-        const unsigned wa = foW[1] + boff, xa = foX[1] + boff, nwa = foW[0] + noff, nxa = foX[0] + noff;
+        const int xs1 = xs == 2 ? 0 : xs + 1;           // slot of stage kt + 1; stage kt + 3 reuses slot xs
+        const unsigned xoff = xs * LX_BYTES, woff = (kt & 1) * LW_BYTES, nxoff = xs1 * LX_BYTES, nwoff = ((kt + 1) & 1) * LW_BYTES;
+        // DMA windows: after the mid-stage barrier of stage s a wave issues W(s+2) x 4 and then X(s+3) x 4; the last two X
+        // pieces go out early in stage s+1 (`tail`, none for the X(2) the prologue issued whole)
+        const bool tail = kt >= 1 && kt + 2 < KT;
+        const bool morew = kt + 2 < KT, morex = kt + 3 < KT, next = kt + 1 < KT;
+        const unsigned wa = foW[1] + woff, xa = foX[1] + xoff, nwa = foW[0] + nwoff, nxa = foX[0] + nxoff;
         IVR_LGKM(4)                     // W + first four X fragments of set 0
         IVR_ROW(xa0, wa0, 0)
-        if (tail) piece(kt + 1, (kt + 1) & 1, 6);
+        if (tail) piece(kt + 2, xs1 == 2 ? 0 : xs1 + 1, 2);
         IVR_ROW(xa0, wa0, 1)
         IVR_RD4(wa1, wa, 0)
         IVR_ROW(xa0, wa0, 2)
-        if (tail) piece(kt + 1, (kt + 1) & 1, 7);
+        if (tail) piece(kt + 2, xs1 == 2 ? 0 : xs1 + 1, 3);
         IVR_ROW(xa0, wa0, 3)
         IVR_RD4(x1lo, xa, 0)
         IVR_LGKM(8)                     // all of set 0
@@ -642,25 +650,30 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
         IVR_RD4(x1hi, xa, 8192)
         IVR_ROW(xa0, wa0, 6)
         IVR_ROW(xa0, wa0, 7)
-        IVR_LGKM(0)                     // this wave has read everything it needs from the stage's buffer
-        if (next) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        IVR_LGKM(0)                     // this wave has read everything it needs from the stage's buffers
+        if (next) {
+            // X(kt+1) and W(kt+1) must have landed; the four youngest pieces in flight are X(kt+2), which may stay
+            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         IVR_ROW(xa1, wa1, 0)
-        if (more) piece(kt + 2, kt & 1, 0);
+        if (morew) piece(kt + 2, 0, 4);
         IVR_ROW(xa1, wa1, 1)
         if (next) { IVR_RD4(wa0, nwa, 0) }
-        if (more) piece(kt + 2, kt & 1, 4);
+        if (morew) piece(kt + 2, 0, 5);
         IVR_ROW(xa1, wa1, 2)
-        if (more) piece(kt + 2, kt & 1, 1);
+        if (morew) piece(kt + 2, 0, 6);
         IVR_ROW(xa1, wa1, 3)
         if (next) { IVR_RD4(x0lo, nxa, 0) }
-        if (more) piece(kt + 2, kt & 1, 5);
+        if (morew) piece(kt + 2, 0, 7);
         IVR_ROW(xa1, wa1, 4)
-        if (more) piece(kt + 2, kt & 1, 2);
+        if (morex) piece(kt + 3, xs, 0);
         IVR_ROW(xa1, wa1, 5)
         if (next) { IVR_RD4(x0hi, nxa, 8192) }
         IVR_ROW(xa1, wa1, 6)
-        if (more) piece(kt + 2, kt & 1, 3);
+        if (morex) piece(kt + 3, xs, 1);
         IVR_ROW(xa1, wa1, 7)
+        xs = xs1;
     }
     IVR_LGKM(0)
     IVR_STAMP(2)
@@ -1508,7 +1521,7 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
         static bool attr_done = false;
         if (!attr_done) {
             IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS));
             attr_done = true;
         }
         const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
@@ -1520,7 +1533,7 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
         else if (EPI == EPI_RESID)
             ga.wide_epi = wide_env && bias_ok && g.N % 64 == 0 && g.ldr % 4 == 0 && reinterpret_cast<uintptr_t>(g.resid) % 16 == 0;
         const int grid = 8 * ((MT + 7) / 8) * NT;
-        hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT>), dim3(grid), dim3(512), BIG_LDS, s, ga);
+        hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT>), dim3(grid), dim3(512), DEEP_LDS, s, ga);
         IVR_LAUNCH_CHECK();
         return IVR_OK;
     }
