@@ -527,10 +527,8 @@ __device__ __forceinline__ void wait_vm_barrier() {
 //   * s_memtime stamps (-DIVR_GEMM_STAMPS, tools/gemm_stamps.py) on a K=768 qkv tile: prologue 2.5k, K loop 30.8k
 //     (2566 cycles per stage, 2048 = MFMA-bound), epilogue 6.7k cycles.
 // ---------------------------------------------------------------------------------------------
-constexpr int LBM = 256, LBN = 256, LX_BYTES = LBM * ROWB, LW_BYTES = LBN * ROWB, LSTAGE = LX_BYTES + LW_BYTES;
-constexpr int BIG_LDS = 2 * LSTAGE;   // 128 KiB (fp8 kernel: two whole stages)
+constexpr int LBM = 256, LBN = 256, LX_BYTES = LBM * ROWB, LW_BYTES = LBN * ROWB;
 constexpr int DEEP_LDS = 3 * LX_BYTES + 2 * LW_BYTES;   // 160 KiB (bf16 / f32 kernel: three X slots, two W slots)
-constexpr int BIG8_LDS = BIG_LDS + 8 * 1024;   // + one dump slot per wave (fp8 kernel)
 
 template <typename T, int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
@@ -820,15 +818,17 @@ __global__ __launch_bounds__(512, 2) void gemm_big8_kernel(GemmArgs g) {
     const v4i rsX = {(int)(unsigned)xb, (int)((xb >> 32) & 0xffff), (int)((int64_t)g.M * g.lda), 0x00020000};
     const v4i rsW = {(int)(unsigned)wb8, (int)((wb8 >> 32) & 0xffff), (int)((int64_t)g.N * g.ldw), 0x00020000};
     const unsigned sx0 = (unsigned)m0 * (unsigned)g.lda, sw0 = (unsigned)n0 * (unsigned)g.ldw;
-    // `on` = false turns the piece into a no-op without a branch (zero-length descriptor: nothing is fetched, and the zeros
-    // it delivers go to a 1 KiB dump slot per wave behind the two stages), which keeps a whole K step in one basic block
-    // for the scheduler barriers below.
-    const unsigned dump = lds0 + BIG_LDS + wave * 1024;
-    auto piece = [&](int kt, int buf, int j, bool on) {
-        const unsigned base = lds0 + buf * LSTAGE + (wave * 4) * 1024, adv = (unsigned)kt * ROWB;
+    // LDS as in the bf16 kernel: three X slots (DMA two stages ahead) + two W slots.  `on` = false turns a piece into a
+    // no-op without a branch (zero-length descriptor: nothing is fetched, zeros are delivered), which keeps a whole K step
+    // in one basic block for the scheduler barriers below and the vmcnt counts uniform.  Disabled pieces only occur for
+    // stages past the end of K, i.e. they write into slots nobody reads any more; the epilogue waits for them (vmcnt(0))
+    // before it reuses the LDS.
+    constexpr int WBASE = 3 * LX_BYTES;
+    auto piece = [&](int kt, int xs, int j, bool on) {
+        const unsigned adv = (unsigned)kt * ROWB;
         v4i rs = j < 4 ? rsX : rsW;
         rs[2] = on ? rs[2] : 0;
-        const unsigned dst = on ? (j < 4 ? base + j * 1024 : base + LX_BYTES + (j - 4) * 1024) : dump;
+        const unsigned dst = j < 4 ? lds0 + xs * LX_BYTES + (wave * 4 + j) * 1024 : lds0 + WBASE + (kt & 1) * LW_BYTES + (wave * 4 + j - 4) * 1024;
         asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(j < 4 ? voffX[j] : voffW[j - 4]), "s"(rs),
                      "s"((j < 4 ? sx0 : sw0) + adv)
                      : "memory", "m0");
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big8_kernel(GemmArgs g) {
     unsigned fo[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) fo[kk] = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
-    const unsigned offX = (wm * 128) * ROWB, offW = LX_BYTES + (wn * 64) * ROWB;
+    const unsigned offX = (wm * 128) * ROWB, offW = WBASE + (wn * 64) * ROWB;
     auto frag = [&](unsigned base, int tile) -> v8i {
         const v4i lo = *reinterpret_cast<const v4i *>(smem + base + fo[0] + tile * 2048);
         const v4i hi = *reinterpret_cast<const v4i *>(smem + base + fo[1] + tile * 2048);
@@ -859,49 +859,55 @@ __global__ __launch_bounds__(512, 2) void gemm_big8_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) piece(0, 0, j, true);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (KT > 1) {
+    // X(1), W(1), then the first half of X(2); every later window is W(s+2) x 4, X(s+3) x 4 with the last two X pieces
+    // issued early in the following stage, so at every mid-stage barrier the four youngest pieces are X two stages ahead
 #pragma unroll
-        for (int j = 0; j < 8; ++j) piece(1, 1, j, true);
-    }
+    for (int j = 0; j < 8; ++j) piece(1, 1, j, KT > 1);
+    piece(2, 2, 0, KT > 2);
+    piece(2, 2, 1, KT > 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) xf[i] = frag(offX, i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) wf[i] = frag(offW, i);
+    int xs = 0;                                          // X slot of stage kt = kt % 3
     for (int kt = 0; kt < KT; ++kt) {
-        const unsigned boff = (kt & 1) * LSTAGE, noff = ((kt + 1) & 1) * LSTAGE;
-        const bool tail = kt >= 1 && kt + 1 < KT;
-        const bool more = kt + 2 < KT;
+        const int xs1 = xs == 2 ? 0 : xs + 1, xs2 = xs1 == 2 ? 0 : xs1 + 1;
+        const unsigned xoff = xs * LX_BYTES + offX, nxoff = xs1 * LX_BYTES + offX, nwoff = ((kt + 1) & 1) * LW_BYTES + offW;
+        const bool on2 = kt + 2 < KT, on3 = kt + 3 < KT;
         IVR_MMA8(0, 0)
-        piece(kt + 1, (kt + 1) & 1, 6, tail);
-        xf[4] = frag(boff + offX, 4);
-        xf[5] = frag(boff + offX, 5);
+        piece(kt + 2, xs2, 2, on2);
+        xf[4] = frag(xoff, 4);
+        xf[5] = frag(xoff, 5);
         IVR_MMA8(1, 0)
-        piece(kt + 1, (kt + 1) & 1, 7, tail);
-        xf[6] = frag(boff + offX, 6);
-        xf[7] = frag(boff + offX, 7);
+        piece(kt + 2, xs2, 3, on2);
+        xf[6] = frag(xoff, 6);
+        xf[7] = frag(xoff, 7);
         IVR_MMA8(2, 0)
         IVR_MMA8(3, 0)
-        // every read of this stage has been issued and must have landed before the buffer is handed to the DMA.
-        // (The loads of the next stage's fragments are unconditional: in the last iteration they fetch stale bytes of the
-        // other buffer that nothing uses - a conditional 8-register update costs a register copy per lane per tile.)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // every read of this stage has been issued and must have landed before its slots are handed to the DMA; X(kt+1) and
+        // W(kt+1) must have landed, the four youngest pieces (X(kt+2)) may stay in flight.
+        // (The loads of the next stage's fragments are unconditional: in the last iteration they fetch stale bytes that
+        // nothing uses - a conditional 8-register update costs a register copy per lane per tile.)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xf[i] = frag(noff + offX, i);
+        for (int i = 0; i < 4; ++i) xf[i] = frag(nxoff, i);
         IVR_MMA8(0, 4)
-        piece(kt + 2, kt & 1, 0, more);
-        wf[0] = frag(noff + offW, 0);
-        piece(kt + 2, kt & 1, 4, more);
+        piece(kt + 2, 0, 4, on2);
+        wf[0] = frag(nwoff, 0);
+        piece(kt + 2, 0, 5, on2);
         IVR_MMA8(1, 4)
-        piece(kt + 2, kt & 1, 1, more);
-        wf[1] = frag(noff + offW, 1);
-        piece(kt + 2, kt & 1, 5, more);
+        piece(kt + 2, 0, 6, on2);
+        wf[1] = frag(nwoff, 1);
+        piece(kt + 2, 0, 7, on2);
         IVR_MMA8(2, 4)
-        piece(kt + 2, kt & 1, 2, more);
-        wf[2] = frag(noff + offW, 2);
+        piece(kt + 3, xs, 0, on3);
+        wf[2] = frag(nwoff, 2);
         IVR_MMA8(3, 4)
-        piece(kt + 2, kt & 1, 3, more);
-        wf[3] = frag(noff + offW, 3);
+        piece(kt + 3, xs, 1, on3);
+        wf[3] = frag(nwoff, 3);
+        xs = xs1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // disabled pieces included: nothing may land in LDS after this
 #undef IVR_MMA8
     __builtin_amdgcn_s_barrier();                             // every wave has read its last fragments
     if (n0 + wn * 64 < g.N)
@@ -1585,7 +1591,7 @@ int launch_gemm8_t(const GemmArgs &g, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big8_kernel<EPI, ACT, OUT8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, BIG8_LDS));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS));
         attr_done = true;
     }
     const int group_env = std::max(0, env_int("IVR_GEMM_GROUP_M", 0));
@@ -1593,7 +1599,7 @@ int launch_gemm8_t(const GemmArgs &g, hipStream_t s) {
     const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
     ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 8);
     ga.wide_epi = 1;
-    hipLaunchKernelGGL((gemm_big8_kernel<EPI, ACT, OUT8>), dim3(8 * ((MT + 7) / 8) * NT), dim3(512), BIG8_LDS, s, ga);
+    hipLaunchKernelGGL((gemm_big8_kernel<EPI, ACT, OUT8>), dim3(8 * ((MT + 7) / 8) * NT), dim3(512), DEEP_LDS, s, ga);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
