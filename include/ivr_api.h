@@ -147,6 +147,10 @@ int ivr_linear_fp8(ivr_ctx *ctx, int epilogue, const void *x /*DEV*/, const void
                    const float *bias /*DEV*/, int M, int N, int K, int act, void *out /*DEV*/, int out_fp8,
                    float *resid /*DEV*/, ivr_stream stream);
 
+/* The weight quantiser of IVR_COMPUTE_FP8, exposed so that it can be checked without a GPU: HOST float32 -> HOST OCP e4m3 bytes
+ * (bias 7, no infinity, max 448), round to nearest even, saturating; NaN -> 0x7f | sign. */
+int ivr_quantize_e4m3_host(const float *src /*HOST*/, uint8_t *dst /*HOST*/, int64_t n);
+
 /* ---- N2 / N3: row L2 normalisation -------------------------------------------------------------
  * Replaces FAISSRetriever._normalize_and_validate_features (core.py:1176-1196) and
  * faiss.normalize_L2 (unified_index.py:1776): x /= ||x||, all-zero rows stay zero.  In place.

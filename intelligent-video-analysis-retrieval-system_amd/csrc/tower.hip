@@ -533,6 +533,12 @@ int ivr_linear_fp8(ivr_ctx *ctx, int epilogue, const void *x, const void *w, con
     return ivr_launch_gemm_fp8(epilogue, g, (hipStream_t)stream);
 }
 
+int ivr_quantize_e4m3_host(const float *src, uint8_t *dst, int64_t n) {
+    IVR_REQUIRE(n >= 0 && (n == 0 || (src && dst)), "ivr_quantize_e4m3_host: NULL argument");
+    for (int64_t i = 0; i < n; ++i) dst[i] = host_e4m3(src[i]);
+    return IVR_OK;
+}
+
 int ivr_tower_debug_hidden(ivr_tower *t, int layer, int n, float *out, ivr_stream) {
     IVR_REQUIRE(t && out, "ivr_tower_debug_hidden: NULL argument");
     std::lock_guard<std::mutex> lk(t->mu);

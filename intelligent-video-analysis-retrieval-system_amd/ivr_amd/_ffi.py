@@ -46,6 +46,7 @@ _SIGS = {
     "ivr_tower_debug_hidden": (_i, [_p, _i, _i, _p, _p]),
     "ivr_tower_workspace_bytes": (_i64, [_p]),
     "ivr_linear": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "ivr_quantize_e4m3_host": (_i, [_p, _p, _i64]),
     "ivr_linear_fp8": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "ivr_l2_normalize": (_i, [_p, _p, _i64, _i, _p, _p]),
     "ivr_index_create": (_i, [_p, _i, _i64, C.POINTER(_p)]),
