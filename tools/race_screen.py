@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Race screen for the hand-synchronised kernels (counted vmcnt + raw barriers): every launch of the same problem must
+reproduce the first result bit for bit, under memory load from a concurrent copy stream.  A DMA that is read one barrier
+too early shows up here as a rare mismatch long before it shows up in a tolerance test."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "intelligent-video-analysis-retrieval-system_amd"))
+import torch  # noqa: E402
+
+from ivr_amd import config as C  # noqa: E402
+from ivr_amd.linear import EPI_RESID, EPI_STORE, linear, linear_fp8, quantize_rows_e4m3  # noqa: E402
+from ivr_amd.tower import Tower  # noqa: E402
+from ivr_amd.weights import make_weights  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+os.environ["IVR_GEMM"] = "4"                     # the 256 x 256 kernels for every shape
+side = torch.cuda.Stream()
+junk_a = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+junk_b = torch.empty_like(junk_a)
+bad = 0
+shapes = [(65536, 768, 3072), (65536, 2304, 768), (4096, 768, 768), (2500, 2304, 768), (3000, 768, 3072), (777, 1024, 4096), (5000, 3072, 768), (300, 320, 128), (256, 256, 256)]
+for (m, n, k) in shapes:
+    g = torch.Generator(device="cuda").manual_seed(m + n + k)
+    x = (torch.randn((m, k), generator=g, device="cuda") * 0.7).to(torch.bfloat16)
+    w = (torch.randn((n, k), generator=g, device="cuda") * k ** -0.5).to(torch.bfloat16)
+    b = torch.randn(n, generator=g, device="cuda")
+    r0 = torch.randn((m, n), generator=g, device="cuda")
+    x8 = x.float().to(torch.float8_e4m3fn)
+    w8, ws = quantize_rows_e4m3(w.float())
+    ref = {}
+    for it in range(iters if m < 20000 else max(8, iters // 8)):
+        with torch.cuda.stream(side):
+            junk_b.copy_(junk_a, non_blocking=True)
+        outs = {"store": linear(x, w, b, act=0), "resid": linear(x, w, b, epilogue=EPI_RESID, resid=r0.clone())}
+        if k % 128 == 0 and n % 64 == 0:
+            outs["fp8"] = linear_fp8(x8, w8, ws, b)
+            outs["fp8_resid"] = linear_fp8(x8, w8, ws, b, epilogue=EPI_RESID, resid=r0.clone())
+            outs["fp8_out8"] = linear_fp8(x8, w8, ws, b, act=0, out_fp8=True).view(torch.uint8)
+        for name, o in outs.items():
+            if it == 0:
+                ref[name] = o.clone()
+            elif not torch.equal(o, ref[name]):
+                bad += 1
+                print(f"MISMATCH {name} M={m} N={n} K={k} iteration {it}: {(o.float() - ref[name].float()).abs().max().item()}")
+    torch.cuda.synchronize()
+    print(f"gemm M={m} N={n} K={k}: {it + 1} launches x {len(outs)} variants reproduced" if not bad else f"gemm M={m} N={n} K={k}: mismatches so far {bad}")
+for name, batch in (("l14", 24), ("dino", 64), ("b32", 256)):
+    cfg = {"b32": C.CLIP_VIT_B32, "l14": C.CLIP_VIT_L14, "dino": C.DINO_VIT_S16}[name]
+    tw = Tower(cfg, make_weights(cfg, 3), max_batch=batch)
+    frames = torch.randint(0, 256, (batch, cfg.image, cfg.image, 3), device="cuda", dtype=torch.uint8)
+    ref = None
+    for it in range(max(10, iters // 10)):
+        with torch.cuda.stream(side):
+            junk_b.copy_(junk_a, non_blocking=True)
+        o = tw.encode_frames(frames)
+        if ref is None:
+            ref = o.clone()
+        elif not torch.equal(o, ref):
+            bad += 1
+            print(f"MISMATCH tower {name} iteration {it}: {(o - ref).abs().max().item()}")
+    print(f"tower {name} batch {batch}: reproduced")
+print("RACE SCREEN", "FAILED" if bad else "clean")
+sys.exit(1 if bad else 0)
