@@ -159,41 +159,37 @@ __device__ __forceinline__ void score_group(const float4 *__restrict__ a, int64_
     for (int q = 0; q < QT; ++q)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // two 16-float chunks per trip: 8 independent 1 KiB loads in flight per wave before the MFMAs
-    int kc = 0;
-    for (; kc + 2 <= kchunks; kc += 2) {
-        float4 av[2][4];
+    // one row tile at a time, eight 16-float chunks per trip: 8 independent 1 KiB loads = 8 KiB CONTIGUOUS in flight per wave
+    // before the MFMAs (a tile is [d/4][16 rows][4 floats], so consecutive chunks of one tile are adjacent in memory).
+    // Per accumulator the K order is ascending whatever the trip shape, so scan and re-score stay bit-identical.
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+    for (int t = 0; t < 4; ++t) {
+        const float4 *at = a + t * tile_stride;
+        int kc = 0;
+        for (; kc + 8 <= kchunks; kc += 8) {
+            float4 av[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) av[u][t] = a[t * tile_stride + (kc + u) * 64];
+            for (int u = 0; u < 8; ++u) av[u] = at[(kc + u) * 64];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    const float4 bv = bload(q, kc + u);
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv.x, acc[q][t], 0, 0, 0);
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv.y, acc[q][t], 0, 0, 0);
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv.z, acc[q][t], 0, 0, 0);
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv.w, acc[q][t], 0, 0, 0);
+                }
+        }
+        for (; kc < kchunks; ++kc) {
+            const float4 av = at[kc * 64];
 #pragma unroll
             for (int q = 0; q < QT; ++q) {
-                const float4 bv = bload(q, kc + u);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t].x, bv.x, acc[q][t], 0, 0, 0);
-                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t].y, bv.y, acc[q][t], 0, 0, 0);
-                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t].z, bv.z, acc[q][t], 0, 0, 0);
-                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t].w, bv.w, acc[q][t], 0, 0, 0);
-                }
-            }
-    }
-    if (kc < kchunks) {
-        float4 av[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) av[t] = a[t * tile_stride + kc * 64];
-#pragma unroll
-        for (int q = 0; q < QT; ++q) {
-            const float4 bv = bload(q, kc);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].x, bv.x, acc[q][t], 0, 0, 0);
-                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].y, bv.y, acc[q][t], 0, 0, 0);
-                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].z, bv.z, acc[q][t], 0, 0, 0);
-                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv.w, acc[q][t], 0, 0, 0);
+                const float4 bv = bload(q, kc);
+                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[q][t], 0, 0, 0);
+                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[q][t], 0, 0, 0);
+                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[q][t], 0, 0, 0);
+                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[q][t], 0, 0, 0);
             }
         }
     }
