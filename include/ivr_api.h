@@ -188,6 +188,11 @@ int ivr_index_reserve_search(ivr_index *idx, int max_nq, int max_k);
  * I: DEV int64 [nq,k] = id_base + row, ties broken by lower id; unused slots (-FLT_MAX, -1). */
 int ivr_index_search(ivr_index *idx, const float *q /*DEV*/, int nq, int k, int normalize_q,
                      int64_t id_base, float *D /*DEV*/, int64_t *I /*DEV*/, ivr_stream stream);
+/* Diagnostics of the bf16 candidate scan behind ivr_index_search: HOST out[0] = 1 when the index keeps a bf16
+ * scan copy, out[1] = number of queries of the LAST scan chunk (<= 64 queries) whose verification failed and which were redone by
+ * the exact float32 scan.  Synchronises the device. */
+int ivr_index_scan_stats(ivr_index *index, int *out /*HOST [2]*/);
+
 /* Merge per-shard candidate lists (the reference's concat + sort of peer results, system.py:1744-1746):
  * D_parts/I_parts DEV [parts, nq, k] with global ids, parts ordered by ascending id range. */
 int ivr_topk_merge(ivr_ctx *ctx, const float *D_parts /*DEV*/, const int64_t *I_parts /*DEV*/, int parts,

@@ -41,11 +41,15 @@ __device__ __forceinline__ float4 load_quad(const float *__restrict__ row, int k
     return v;
 }
 
-// one wave per 16-row tile; lane l owns row (l & 15) and quad (l >> 4) of every 16-float chunk
+// one wave per 16-row tile; lane l owns row (l & 15) and quad (l >> 4) of every 16-float chunk.
+// Optionally also writes the bf16 scan copy of the tile (dst16; and the rounding remainder dst16lo for query tiles):
+// per 32 floats of K one 1 KiB piece, lane l -> 16 bytes = the two quads this lane owns in the pair of 16-float chunks, i.e.
+// the operand of one v_mfma_f32_16x16x32_bf16 with K permuted the same way for index rows and queries.
 __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                         int64_t row_start, int64_t n, int d, int dp4,
                                                         int normalize, int32_t *__restrict__ nonfinite,
-                                                        const int64_t *__restrict__ start_dev) {
+                                                        const int64_t *__restrict__ start_dev, uint4 *__restrict__ dst16,
+                                                        uint4 *__restrict__ dst16lo, unsigned int *__restrict__ maxnorm_bits) {
     if (start_dev) row_start = *start_dev;          // ring cursor kept in HBM so a captured graph can replay it
     const int lane = threadIdx.x & 63;
     const int64_t tile0 = row_start >> 4;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict_
     const int kchunks = dp4 >> 2;
     float ss = 0.f;
     int bad = 0;
-    if (normalize || nonfinite) {
+    if (normalize || nonfinite || maxnorm_bits) {
         for (int kc = 0; kc < kchunks; ++kc) {
             const int k0 = kc * 16 + qd * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -82,19 +86,53 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict_
     }
     // core.py:1194-1196: norms[norms == 0] = 1; features / norms
     const float nrm = normalize ? (ss > 0.f ? sqrtf(ss) : 1.f) : 1.f;
+    if (maxnorm_bits) {
+        // largest stored row norm (an upper bound: overwritten rows keep counting), for the error bound of the bf16 scan;
+        // a normalised row is 1 up to rounding, the 1e-6 covers it.  Positive floats order like their bit patterns.
+        float stored = valid ? (normalize ? (ss > 0.f ? 1.000001f : 0.f) : sqrtf(ss)) : 0.f;
+        if (!(stored == stored)) stored = INFINITY;      // NaN rows: no bound -> the verification always fails over to the exact path
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) stored = fmaxf(stored, __shfl_xor(stored, o, 64));
+        const unsigned int bits = __float_as_uint(stored);
+        if (lane == 0 && bits > *maxnorm_bits) atomicMax(maxnorm_bits, bits);
+    }
     float4 *out = reinterpret_cast<float4 *>(dst) + tile * (int64_t)dp4 * 16 + lane;
-    for (int kc = 0; kc < kchunks; ++kc) {
-        const int k0 = kc * 16 + qd * 4;
-        if (valid) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k0 < d) v = load_quad(srow, k0, d, vec && k0 + 3 < d);
-            if (normalize) {
-                v.x /= nrm;
-                v.y /= nrm;
-                v.z /= nrm;
-                v.w /= nrm;
+    const int pieces = (kchunks + 1) >> 1;
+    for (int kb = 0; kb < pieces; ++kb) {
+        float4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kc = 2 * kb + u, k0 = kc * 16 + qd * 4;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && kc < kchunks) {
+                if (k0 < d) v[u] = load_quad(srow, k0, d, vec && k0 + 3 < d);
+                if (normalize) {
+                    v[u].x /= nrm;
+                    v[u].y /= nrm;
+                    v[u].z /= nrm;
+                    v[u].w /= nrm;
+                }
+                out[kc * 64] = v[u];
             }
-            out[kc * 64] = v;
+        }
+        if (dst16 && valid) {
+            uint4 hi;
+            hi.x = ivr_pack_bf16x2(v[0].x, v[0].y);
+            hi.y = ivr_pack_bf16x2(v[0].z, v[0].w);
+            hi.z = ivr_pack_bf16x2(v[1].x, v[1].y);
+            hi.w = ivr_pack_bf16x2(v[1].z, v[1].w);
+            dst16[(tile * pieces + kb) * 64 + lane] = hi;
+            if (dst16lo) {
+                auto lo2 = [](uint32_t h, float a, float b) {
+                    return ivr_pack_bf16x2(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+                };
+                uint4 lo;
+                lo.x = lo2(hi.x, v[0].x, v[0].y);
+                lo.y = lo2(hi.y, v[0].z, v[0].w);
+                lo.z = lo2(hi.z, v[1].x, v[1].y);
+                lo.w = lo2(hi.w, v[1].z, v[1].w);
+                dst16lo[(tile * pieces + kb) * 64 + lane] = lo;
+            }
         }
     }
 }
@@ -200,8 +238,15 @@ template <int QT>
 __global__ __launch_bounds__(512) void scan_groupmax_kernel(const float *__restrict__ data,
                                                             const float *__restrict__ qtiled, int dp4,
                                                             int64_t ngroups, int64_t ntotal,
-                                                            float *__restrict__ gmax, int64_t mstride) {
+                                                            float *__restrict__ gmax, int64_t mstride,
+                                                            const int *__restrict__ tile_flag) {
     extern __shared__ __attribute__((aligned(16))) float4 qs[];
+    if (tile_flag) {       // fallback pass behind the bf16 candidate scan: only query tiles that failed their verification
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < QT; ++i) any |= tile_flag[i] != 0;
+        if (!any) return;
+    }
     const int per_tile = dp4 * 16;   // float4 per 16-row tile
     for (int i = threadIdx.x; i < QT * per_tile; i += blockDim.x) qs[i] = reinterpret_cast<const float4 *>(qtiled)[i];
     __syncthreads();
@@ -231,16 +276,126 @@ __global__ __launch_bounds__(512) void scan_groupmax_kernel(const float *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 candidate scan (half the index bytes per pass): group maxima of  <bf16(row), q_hi + q_lo>  on v_mfma_f32_16x16x32_bf16.
+// The result only RANKS groups; every reported score comes from the exact float32 re-score.  Exactness is kept by a check:
+// with e = |approx - exact| <= (2^-8 + 2^-15 + dp 2^-23) |row| |q|  (bf16 rounding of the row, the dropped q remainder, f32
+// accumulation), all rows of a group excluded after the kp best approximate maxima score <= (kp+1)-th approximate maximum + e.
+// If that is strictly below the k-th exact score found among the kp re-scored groups, no excluded row can enter or tie the
+// top k.  Queries that fail the check are redone by the exact float32 scan (same launch sequence, predicated on device).
+// ---------------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(512) void scan16_groupmax_kernel(const uint4 *__restrict__ data16, const uint4 *__restrict__ qhi,
+                                                              const uint4 *__restrict__ qlo, int pieces, int64_t ngroups,
+                                                              int64_t ntotal, float *__restrict__ gmax, int64_t mstride) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) uint4 qs16[];      // [QT][2][pieces][64]
+    const int per_q = pieces * 64;
+    for (int i = threadIdx.x; i < QT * per_q; i += blockDim.x) {
+        const int q = i / per_q, r = i - q * per_q;
+        qs16[(q * 2) * per_q + r] = qhi[i];
+        qs16[(q * 2 + 1) * per_q + r] = qlo[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int64_t g = (int64_t)blockIdx.x * nw + wave; g < ngroups; g += (int64_t)gridDim.x * nw) {
+        f32x4 acc[QT][4];
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint4 *a = data16 + g * 4 * (int64_t)per_q + lane;
+        // K outermost: a query fragment pair (hi, lo) is read from LDS once and used for the four row tiles (one LDS read per
+        // four MFMAs; tile-outermost it is one per MFMA, which saturates the LDS port from two query tiles on)
+        int kb = 0;
+        for (; kb + 2 <= pieces; kb += 2) {
+            uint4 av[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) av[u][t] = a[(t * pieces + kb + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    const uint4 bh = qs16[(q * 2) * per_q + (kb + u) * 64 + lane], bl = qs16[(q * 2 + 1) * per_q + (kb + u) * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[u][t]), __builtin_bit_cast(bf16x8_t, bh), acc[q][t], 0, 0, 0);
+                        acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[u][t]), __builtin_bit_cast(bf16x8_t, bl), acc[q][t], 0, 0, 0);
+                    }
+                }
+        }
+        for (; kb < pieces; ++kb) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint4 av = a[(t * pieces + kb) * 64];
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    const uint4 bh = qs16[(q * 2) * per_q + kb * 64 + lane], bl = qs16[(q * 2 + 1) * per_q + kb * 64 + lane];
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bh), acc[q][t], 0, 0, 0);
+                    acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bl), acc[q][t], 0, 0, 0);
+                }
+            }
+        }
+        const bool partial = (g + 1) * kGroupRows > ntotal;   // wave-uniform: only the last group
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            float m = -FLT_MAX;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = acc[q][t][r];
+                    if (partial && g * kGroupRows + t * 16 + (lane >> 4) * 4 + r >= ntotal) s = -FLT_MAX;
+                    m = fmaxf(m, s);
+                }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            if (lane < 16) gmax[(int64_t)(q * 16 + lane) * mstride + g] = m;
+        }
+    }
+}
+
+// one thread per query of the chunk: does the (kp+1)-th approximate group maximum + error bound stay strictly below the k-th
+// exact score?  ok[q] = 1 keeps the fast result; otherwise the query's tile is flagged for the exact pass.
+__global__ __launch_bounds__(64) void verify_candidates_kernel(const float *__restrict__ gmax, int64_t mstride, const uint32_t *__restrict__ sel,
+                                                               int ksel2, int kp, const float *__restrict__ D, int k, int nq,
+                                                               const float *__restrict__ qtiled, int dp4, float rel_eps,
+                                                               const unsigned int *__restrict__ maxnorm_bits, int *__restrict__ ok,
+                                                               int *__restrict__ tile_flag) {
+    const int q = threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t g = sel[(int64_t)q * ksel2 + kp];
+    int good = 1;
+    if (g != 0xFFFFFFFFu) {                       // there IS an excluded group
+        // |q| from the tiled float32 query (query q of tile q >> 4: float4 number kq * 16 + (q & 15) of the tile)
+        const float4 *qt = reinterpret_cast<const float4 *>(qtiled) + (int64_t)(q >> 4) * dp4 * 16 + (q & 15);
+        float ss = 0.f;
+        for (int kq = 0; kq < dp4; ++kq) {
+            const float4 v = qt[kq * 16];
+            ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
+        }
+        const float bound = gmax[(int64_t)q * mstride + g] + rel_eps * sqrtf(ss) * __uint_as_float(*maxnorm_bits);
+        const float kth = D[(int64_t)q * k + (k - 1)];
+        good = bound < kth;                        // false for NaN / inf bounds too
+    }
+    ok[q] = good;
+    if (!good) atomicOr(&tile_flag[q >> 4], 1);
+}
+
 // pass 3: one wave per (query, selected group).  cand[q][j*64 + row] = key(score, row id)
 __global__ __launch_bounds__(256) void rescore_groups_kernel(const float *__restrict__ data,
                                                              const float *__restrict__ qtiled, int dp4,
                                                              int64_t ntotal, const uint32_t *__restrict__ sel,
-                                                             int ksel, int nq, uint64_t *__restrict__ cand) {
+                                                             int sel_stride, int ksel, int nq, uint64_t *__restrict__ cand,
+                                                             const int *__restrict__ skip) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (int64_t)nq * ksel) return;
     const int q = (int)(w / ksel), j = (int)(w % ksel);
-    const uint32_t g = sel[(int64_t)q * ksel + j];
+    if (skip && skip[q]) return;
+    const uint32_t g = sel[(int64_t)q * sel_stride + j];
     uint64_t *out = cand + ((int64_t)q * ksel + j) * kGroupRows;
     if (g == 0xFFFFFFFFu) {   // fewer groups than k
         out[lane] = 0;
@@ -304,7 +459,9 @@ template <typename Src, int OUT>
 __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int qcol0, int k, int64_t id_base,
                                                                   uint32_t *__restrict__ out_groups,
                                                                   float *__restrict__ D, int64_t *__restrict__ I,
-                                                                  const int64_t *__restrict__ I_parts) {
+                                                                  const int64_t *__restrict__ I_parts,
+                                                                  const int *__restrict__ skip = nullptr) {
+    if (skip && skip[blockIdx.x]) return;          // whole block: this query kept its fast-path result
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix, s_mask;
     __shared__ unsigned int s_kth, s_cnt, s_valid;
@@ -481,35 +638,58 @@ struct ivr_index {
     uint32_t *sel = nullptr;         // [nq][ksel]
     uint64_t *cand = nullptr;        // [nq][ksel*64]
     int64_t sel_cap = 0;             // in (nq*ksel) units
+    // bf16 candidate scan (scan16_groupmax_kernel): scan copy of the rows, split queries, verification state
+    bool scan16 = false;             // IVR_SCAN_BF16 (default on), fixed at creation
+    int pieces = 0;                  // 1 KiB pieces of a 16-row tile = ceil(dp / 32)
+    uint4 *data16 = nullptr;         // [cap/16][pieces][64]
+    uint4 *q16hi = nullptr, *q16lo = nullptr;   // [qtiles][pieces][64]
+    unsigned int *maxnorm = nullptr; // DEV: bits of the largest stored row norm
+    int *okflag = nullptr;           // DEV [64] per scan chunk + [4] tile flags behind it
+    int last_nqc = 0;                // queries of the last chunk that went through the candidate scan
 };
 
 namespace {
 
 int64_t tile_bytes(const ivr_index *x, int64_t rows) { return rows * (int64_t)x->dp * 4; }
 
+int64_t tile16_bytes(const ivr_index *x, int64_t rows) { return (rows / 16) * (int64_t)x->pieces * 1024; }
+
 int index_alloc(ivr_index *x, int64_t rows) {
     rows = ivr_round_up(std::max<int64_t>(rows, kGroupRows), kGroupRows);
     float *nd = nullptr;
     IVR_HIP(hipMalloc(&nd, (size_t)tile_bytes(x, rows)));
     IVR_HIP(hipMemset(nd, 0, (size_t)tile_bytes(x, rows)));
+    uint4 *nd16 = nullptr;
+    if (x->scan16) {
+        IVR_HIP(hipMalloc(&nd16, (size_t)tile16_bytes(x, rows)));
+        IVR_HIP(hipMemset(nd16, 0, (size_t)tile16_bytes(x, rows)));
+    }
     if (x->data) {
-        if (x->ntotal > 0)
+        if (x->ntotal > 0) {
             IVR_HIP(hipMemcpy(nd, x->data, (size_t)tile_bytes(x, ivr_round_up(x->ntotal, 16)), hipMemcpyDeviceToDevice));
+            if (x->scan16)
+                IVR_HIP(hipMemcpy(nd16, x->data16, (size_t)tile16_bytes(x, ivr_round_up(x->ntotal, 16)), hipMemcpyDeviceToDevice));
+        }
         IVR_HIP(hipFree(x->data));
+        if (x->data16) IVR_HIP(hipFree(x->data16));
     }
     x->data = nd;
+    x->data16 = nd16;
     x->cap = rows;
     return IVR_OK;
 }
 
+// dst == x->data: index rows (bf16 scan copy + max norm alongside); dst == x->qtiled: queries (bf16 hi / lo split alongside)
 int launch_tile_rows(ivr_index *x, float *dst, const float *src, int64_t start, int64_t n, int normalize,
-                     int32_t *nonfinite, hipStream_t s) {
+                     int32_t *nonfinite, hipStream_t s, const int64_t *start_dev = nullptr, int64_t max_tiles = 0) {
     if (n <= 0) return IVR_OK;
-    const int64_t ntiles = ((start + n + 15) >> 4) - (start >> 4);
+    const int64_t ntiles = max_tiles ? max_tiles : ((start + n + 15) >> 4) - (start >> 4);
     const unsigned grid = (unsigned)ivr_ceil_div(ntiles, 4);
-    IvrProf prof("tile_rows", s, (double)n * (x->d + x->dp) * 4);
-    hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, src, dst, start, n, x->d, x->dp4, normalize, nonfinite,
-                       (const int64_t *)nullptr);
+    const bool rows = dst == x->data;
+    IvrProf prof("tile_rows", s, (double)n * (x->d + x->dp) * 4 + (x->scan16 ? (double)n * x->pieces * 64 * (rows ? 1 : 2) : 0.0));
+    hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, src, dst, start, n, x->d, x->dp4, normalize, nonfinite, start_dev,
+                       x->scan16 ? (rows ? x->data16 : x->q16hi) : (uint4 *)nullptr, x->scan16 && !rows ? x->q16lo : (uint4 *)nullptr,
+                       x->scan16 && rows ? x->maxnorm : (unsigned int *)nullptr);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
@@ -518,6 +698,8 @@ int sel_threads(int64_t n) { return n <= 16 * 256 ? 256 : kSelThreads; }
 
 // choose the query tile width of the scan (queries per index pass = 16*QT)
 int pick_qt(int nq) { return nq <= 16 ? 1 : nq <= 32 ? 2 : nq <= 48 ? 3 : 4; }
+// groups re-scored exactly behind the bf16 candidate scan: k plus slack for what the approximate ranking may displace
+int fast_groups(int k) { return k + std::max(22, k); }
 
 int reserve_search(ivr_index *x, int nq, int k) {
     const int qtiles = (int)ivr_ceil_div(nq, 16);
@@ -528,6 +710,14 @@ int reserve_search(ivr_index *x, int nq, int k) {
         const int want = std::max(qtiles, 4);
         IVR_HIP(hipMalloc(&x->qtiled, (size_t)want * 16 * x->dp * 4));
         IVR_HIP(hipMemset(x->qtiled, 0, (size_t)want * 16 * x->dp * 4));
+        if (x->scan16) {
+            if (x->q16hi) IVR_HIP(hipFree(x->q16hi));
+            if (x->q16lo) IVR_HIP(hipFree(x->q16lo));
+            IVR_HIP(hipMalloc(&x->q16hi, (size_t)want * x->pieces * 1024));
+            IVR_HIP(hipMalloc(&x->q16lo, (size_t)want * x->pieces * 1024));
+            IVR_HIP(hipMemset(x->q16hi, 0, (size_t)want * x->pieces * 1024));
+            IVR_HIP(hipMemset(x->q16lo, 0, (size_t)want * x->pieces * 1024));
+        }
         x->qtiles_cap = want;
     }
     const int64_t mstride = ivr_round_up(x->cap / kGroupRows, 64);
@@ -539,7 +729,7 @@ int reserve_search(ivr_index *x, int nq, int k) {
         IVR_HIP(hipMalloc(&x->gmax, (size_t)need_gmax * 4));
         x->gmax_floats = need_gmax;
     }
-    const int64_t need_sel = (int64_t)std::min(nq, 64) * k;   // per scan chunk
+    const int64_t need_sel = (int64_t)std::min(nq, 64) * (x->scan16 ? fast_groups(k) + 1 : k);   // per scan chunk
     if (need_sel > x->sel_cap) {
         if (x->sel) IVR_HIP(hipFree(x->sel));
         if (x->cand) IVR_HIP(hipFree(x->cand));
@@ -554,7 +744,7 @@ int reserve_search(ivr_index *x, int nq, int k) {
 }
 
 template <int QT>
-void launch_scan(ivr_index *x, const float *qt, int64_t ngroups, int64_t mstride, hipStream_t s) {
+void launch_scan(ivr_index *x, const float *qt, int64_t ngroups, int64_t mstride, hipStream_t s, const int *tile_flag = nullptr) {
     const size_t lds = (size_t)QT * 16 * x->dp * 4;
     // 8 waves per workgroup share one staged query tile; size the grid so every CU holds as many
     // workgroups as the LDS allows and let each wave stride over the groups
@@ -567,7 +757,22 @@ void launch_scan(ivr_index *x, const float *qt, int64_t ngroups, int64_t mstride
     // algorithmic bytes: every stored row once + the query tile + one maximum per (group, query)
     IvrProf prof("scan_groupmax", s, (double)x->ntotal * x->dp * 4 + (double)QT * 16 * x->dp * 4 + (double)ngroups * QT * 16 * 4);
     hipLaunchKernelGGL(scan_groupmax_kernel<QT>, dim3((unsigned)grid), dim3(threads), lds, s, x->data, qt, x->dp4, ngroups,
-                       x->ntotal, x->gmax, mstride);
+                       x->ntotal, x->gmax, mstride, tile_flag);
+}
+
+template <int QT>
+void launch_scan16(ivr_index *x, int64_t tile0, int64_t ngroups, int64_t mstride, hipStream_t s) {
+    const size_t lds = (size_t)QT * 2 * x->pieces * 1024;
+    const int threads = 512, nw = threads / 64;
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds, 1)));
+    int64_t grid = std::min<int64_t>(ivr_ceil_div(ngroups, nw), (int64_t)x->ctx->cu_count * per_cu);
+    grid = std::max<int64_t>(grid, 1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scan16_groupmax_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    // algorithmic bytes: the bf16 copy of every stored row once + the split query tiles + one maximum per (group, query)
+    IvrProf prof("scan16_groupmax", s, (double)x->ntotal * x->pieces * 64 + (double)QT * 2 * x->pieces * 1024 + (double)ngroups * QT * 16 * 4);
+    hipLaunchKernelGGL(scan16_groupmax_kernel<QT>, dim3((unsigned)grid), dim3(threads), lds, s, x->data16, x->q16hi + tile0 * x->pieces * 64,
+                       x->q16lo + tile0 * x->pieces * 64, x->pieces, ngroups, x->ntotal, x->gmax, mstride);
 }
 
 }  // namespace
@@ -585,6 +790,17 @@ int ivr_index_create(ivr_ctx *ctx, int d, int64_t capacity_rows, ivr_index **out
     x->d = d;
     x->dp = (int)ivr_round_up(d, 16);
     x->dp4 = x->dp / 4;
+    x->pieces = (x->dp + 31) / 32;
+    {
+        const char *e = getenv("IVR_SCAN_BF16");       // A/B switch, read when the index is created
+        x->scan16 = !(e && e[0] == '0');   // LDS per 16-query tile (hi + lo) = 64 dp bytes, the same as the float32 scan's
+    }
+    if (x->scan16) {
+        IVR_HIP(hipMalloc(&x->maxnorm, 4));
+        IVR_HIP(hipMemset(x->maxnorm, 0, 4));
+        IVR_HIP(hipMalloc(&x->okflag, 68 * sizeof(int)));
+        IVR_HIP(hipMemset(x->okflag, 0, 68 * sizeof(int)));
+    }
     int rc = index_alloc(x, capacity_rows);
     if (rc != IVR_OK) {
         delete x;
@@ -601,6 +817,8 @@ int ivr_index_destroy(ivr_index *x) {
     if (x->gmax) (void)hipFree(x->gmax);
     if (x->sel) (void)hipFree(x->sel);
     if (x->cand) (void)hipFree(x->cand);
+    for (void *p : {(void *)x->data16, (void *)x->q16hi, (void *)x->q16lo, (void *)x->maxnorm, (void *)x->okflag})
+        if (p) (void)hipFree(p);
     delete x;
     return IVR_OK;
 }
@@ -610,6 +828,10 @@ int ivr_index_reset(ivr_index *x) {
     std::lock_guard<std::mutex> lk(x->mu);
     IVR_HIP(hipSetDevice(x->ctx->device));
     IVR_HIP(hipMemset(x->data, 0, (size_t)tile_bytes(x, x->cap)));
+    if (x->scan16) {
+        IVR_HIP(hipMemset(x->data16, 0, (size_t)tile16_bytes(x, x->cap)));
+        IVR_HIP(hipMemset(x->maxnorm, 0, 4));
+    }
     x->ntotal = 0;
     return IVR_OK;
 }
@@ -654,13 +876,8 @@ int ivr_index_write_ring(ivr_index *x, const float *rows, int64_t n, int normali
     IVR_HIP(hipSetDevice(x->ctx->device));
     hipStream_t s = (hipStream_t)stream;
     // the cursor is only known on the device: launch for the worst-case number of touched tiles
-    const unsigned grid = (unsigned)ivr_ceil_div(ivr_ceil_div(n, 16) + 1, 4);
-    {
-        IvrProf prof("tile_rows", s, (double)n * (x->d + x->dp) * 4);
-        hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, rows, x->data, (int64_t)0, n, x->d, x->dp4, normalize,
-                           (int32_t *)nullptr, (const int64_t *)cursor);
-    }
-    IVR_LAUNCH_CHECK();
+    int rc = launch_tile_rows(x, x->data, rows, 0, n, normalize, nullptr, s, cursor, ivr_ceil_div(n, 16) + 1);
+    if (rc != IVR_OK) return rc;
     hipLaunchKernelGGL(advance_cursor_kernel, dim3(1), dim3(1), 0, s, cursor, n, x->ntotal);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
@@ -711,40 +928,108 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
     // queries per index pass: as many 16-query tiles as fit 128 KiB of LDS, at most 4
     const int qt_max = (int)std::max<int64_t>(1, std::min<int64_t>(4, (128 * 1024) / ((int64_t)16 * x->dp * 4)));
     const int chunk = 16 * qt_max;
-    for (int q0 = 0; q0 < nq; q0 += chunk) {
-        const int nqc = std::min(chunk, nq - q0);
-        const int qt = pick_qt(nqc);
-        const float *qtile = x->qtiled + (int64_t)(q0 / 16) * 16 * x->dp;
+    // bf16 candidate scan first when it can pay: enough groups that kp of them are a small fraction, k within the selector's
+    // range.  Its result is verified per query on the device; failures are redone by the exact pass below (tile_flag / skip).
+    const int kp = fast_groups(k);
+    const bool fast = x->scan16 && ngroups >= 4 * (int64_t)(kp + 1) && kp + 1 <= IVR_MAX_K;
+    // bf16 keeps 8 significant bits: |row - bf16(row)| <= 2^-8 |row| per element; the query's hi + lo leaves 2^-16; f32 accumulation
+    const float rel_eps = (0.00390625f + 0.0000306f + (float)x->dp * 1.2e-7f) * 1.01f;
+    int *ok = x->okflag, *tile_flag = x->okflag ? x->okflag + 64 : nullptr;
+    auto exact_pass = [&](const float *qtile, int nqc, int qt, int q0, const int *flags, const int *skip) -> int {
         if (ngroups > 0) {
             switch (qt) {
-                case 1: launch_scan<1>(x, qtile, ngroups, mstride, s); break;
-                case 2: launch_scan<2>(x, qtile, ngroups, mstride, s); break;
-                case 3: launch_scan<3>(x, qtile, ngroups, mstride, s); break;
-                default: launch_scan<4>(x, qtile, ngroups, mstride, s); break;
+                case 1: launch_scan<1>(x, qtile, ngroups, mstride, s, flags); break;
+                case 2: launch_scan<2>(x, qtile, ngroups, mstride, s, flags); break;
+                case 3: launch_scan<3>(x, qtile, ngroups, mstride, s, flags); break;
+                default: launch_scan<4>(x, qtile, ngroups, mstride, s, flags); break;
             }
             IVR_LAUNCH_CHECK();
         }
         SrcGroupMax sg{x->gmax, mstride, ngroups};
         {
-        IvrProf prof("select_groups", s, (double)nqc * ngroups * 4);
-        hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(sel_threads(ngroups)), 0, s, sg, 0, ksel,
-                           (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr);
+            IvrProf prof("select_groups", s, (double)nqc * ngroups * 4);
+            hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(sel_threads(ngroups)), 0, s, sg, 0, ksel,
+                               (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr, skip);
         }
         IVR_LAUNCH_CHECK();
         const int64_t waves = (int64_t)nqc * ksel;
         // rescore reads query tile (q >> 4) relative to the chunk's first tile
         {
-        IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4);
-        hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)ivr_ceil_div(waves, 4)), dim3(256), 0, s, x->data, qtile,
-                           x->dp4, x->ntotal, x->sel, ksel, nqc, x->cand);
+            IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4);
+            hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)ivr_ceil_div(waves, 4)), dim3(256), 0, s, x->data, qtile, x->dp4,
+                               x->ntotal, x->sel, ksel, ksel, nqc, x->cand, skip);
         }
         IVR_LAUNCH_CHECK();
         SrcKeys sk{x->cand, (int64_t)ksel * kGroupRows};
         IvrProf prof("select_final", s, (double)waves * kGroupRows * 8);
-        hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(sel_threads((int64_t)ksel * kGroupRows)), 0, s, sk, 0, k, id_base,
-                           (uint32_t *)nullptr, D + (int64_t)q0 * k, I + (int64_t)q0 * k, (const int64_t *)nullptr);
+        hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(sel_threads((int64_t)ksel * kGroupRows)), 0, s, sk, 0, k,
+                           id_base, (uint32_t *)nullptr, D + (int64_t)q0 * k, I + (int64_t)q0 * k, (const int64_t *)nullptr, skip);
         IVR_LAUNCH_CHECK();
+        return IVR_OK;
+    };
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int nqc = std::min(chunk, nq - q0);
+        const int qt = pick_qt(nqc);
+        const float *qtile = x->qtiled + (int64_t)(q0 / 16) * 16 * x->dp;
+        if (!fast) {
+            x->last_nqc = 0;
+            rc = exact_pass(qtile, nqc, qt, q0, nullptr, nullptr);
+            if (rc != IVR_OK) return rc;
+            continue;
+        }
+        IVR_HIP(hipMemsetAsync(tile_flag, 0, 4 * sizeof(int), s));
+        x->last_nqc = nqc;
+        switch (qt) {
+            case 1: launch_scan16<1>(x, q0 / 16, ngroups, mstride, s); break;
+            case 2: launch_scan16<2>(x, q0 / 16, ngroups, mstride, s); break;
+            case 3: launch_scan16<3>(x, q0 / 16, ngroups, mstride, s); break;
+            default: launch_scan16<4>(x, q0 / 16, ngroups, mstride, s); break;
+        }
+        IVR_LAUNCH_CHECK();
+        const int ksel2 = kp + 1;
+        SrcGroupMax sg{x->gmax, mstride, ngroups};
+        {
+            IvrProf prof("select_groups", s, (double)nqc * ngroups * 4);
+            hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(sel_threads(ngroups)), 0, s, sg, 0, ksel2,
+                               (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr, (const int *)nullptr);
+        }
+        IVR_LAUNCH_CHECK();
+        const int64_t waves = (int64_t)nqc * kp;
+        {
+            IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4);
+            hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)ivr_ceil_div(waves, 4)), dim3(256), 0, s, x->data, qtile, x->dp4,
+                               x->ntotal, x->sel, ksel2, kp, nqc, x->cand, (const int *)nullptr);
+        }
+        IVR_LAUNCH_CHECK();
+        {
+            SrcKeys sk{x->cand, (int64_t)kp * kGroupRows};
+            IvrProf prof("select_final", s, (double)waves * kGroupRows * 8);
+            hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(sel_threads((int64_t)kp * kGroupRows)), 0, s, sk, 0, k,
+                               id_base, (uint32_t *)nullptr, D + (int64_t)q0 * k, I + (int64_t)q0 * k, (const int64_t *)nullptr,
+                               (const int *)nullptr);
+        }
+        IVR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(verify_candidates_kernel, dim3(1), dim3(64), 0, s, x->gmax, mstride, x->sel, ksel2, kp, D + (int64_t)q0 * k, k, nqc,
+                           qtile, x->dp4, rel_eps, x->maxnorm, ok, tile_flag);
+        IVR_LAUNCH_CHECK();
+        // exact pass for the queries whose check failed: every kernel below exits at once when nothing is flagged
+        rc = exact_pass(qtile, nqc, qt, q0, tile_flag, ok);
+        if (rc != IVR_OK) return rc;
     }
+    return IVR_OK;
+}
+
+int ivr_index_scan_stats(ivr_index *x, int *out) {
+    IVR_REQUIRE(x && out, "ivr_index_scan_stats: NULL argument");
+    std::lock_guard<std::mutex> lk(x->mu);
+    out[0] = x->scan16 ? 1 : 0;
+    out[1] = 0;
+    if (!x->scan16) return IVR_OK;
+    IVR_HIP(hipSetDevice(x->ctx->device));
+    IVR_HIP(hipDeviceSynchronize());
+    int ok[64];
+    IVR_HIP(hipMemcpy(ok, x->okflag, sizeof(ok), hipMemcpyDeviceToHost));
+    for (int i = 0; i < x->last_nqc; ++i) out[1] += ok[i] == 0;
     return IVR_OK;
 }
 

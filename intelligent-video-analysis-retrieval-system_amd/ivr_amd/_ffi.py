@@ -51,6 +51,7 @@ _SIGS = {
     "ivr_l2_normalize": (_i, [_p, _p, _i64, _i, _p, _p]),
     "ivr_index_create": (_i, [_p, _i, _i64, C.POINTER(_p)]),
     "ivr_index_destroy": (_i, [_p]),
+    "ivr_index_scan_stats": (_i, [_p, _p]),
     "ivr_index_reset": (_i, [_p]),
     "ivr_index_ntotal": (_i64, [_p]),
     "ivr_index_dim": (_i, [_p]),

@@ -73,6 +73,12 @@ class FlatIPIndex:
     def ntotal(self):
         return int(self._lib.ivr_index_ntotal(self._h))
 
+    def scan_stats(self):
+        """(has_bf16_scan_copy, queries of the last scan chunk that were redone by the exact float32 scan)."""
+        out = (C.c_int * 2)()
+        _ffi.check(self._lib.ivr_index_scan_stats(self._h, out), "ivr_index_scan_stats")
+        return bool(out[0]), int(out[1])
+
     def train(self, x):  # core.py:817-820 calls train() when is_trained is False; flat indexes never need it
         return None
 
