@@ -365,6 +365,8 @@ __global__ __launch_bounds__(64) void verify_candidates_kernel(const float *__re
                                                                const unsigned int *__restrict__ maxnorm_bits, int *__restrict__ ok,
                                                                int *__restrict__ tile_flag) {
     const int q = threadIdx.x;
+    if (q < 4) tile_flag[q] = 0;                   // this kernel owns the flags of its chunk: reset, then raise
+    __syncthreads();
     if (q >= nq) return;
     const uint32_t g = sel[(int64_t)q * ksel2 + kp];
     int good = 1;
@@ -977,7 +979,6 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
             if (rc != IVR_OK) return rc;
             continue;
         }
-        IVR_HIP(hipMemsetAsync(tile_flag, 0, 4 * sizeof(int), s));
         x->last_nqc = nqc;
         switch (qt) {
             case 1: launch_scan16<1>(x, q0 / 16, ngroups, mstride, s); break;

@@ -47,4 +47,5 @@ for use_graph in (True, False):
     ms = (time.perf_counter() - t0) / steps * 1e3
     budget = fpf / 30.0 * 1e3
     print(f"{'hipGraph replay' if use_graph else 'plain launches '}: {ms:7.3f} ms per step of {n} frames ({feeds} feeds x {fpf}) + top-10 of {nq} queries "
-          f"over {rows} rows; real-time budget {budget:.1f} ms -> {budget / ms:.1f}x margin; {rows * nq / (ms * 1e-3) / 1e9:.1f} G pairs/s incl. embed")
+          f"over {rows} rows; real-time budget {budget:.1f} ms -> {budget / ms:.1f}x margin; {rows * nq / (ms * 1e-3) / 1e9:.1f} G pairs/s incl. embed; "
+          f"bf16 scan copy / queries redone exactly in the last step: {index.scan_stats()}")
