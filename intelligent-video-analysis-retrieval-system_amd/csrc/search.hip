@@ -504,11 +504,90 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
     }
     __syncthreads();
     const unsigned int keff = min((unsigned int)k, s_valid);
-    if (cached && keff <= 64) {
+    __shared__ uint64_t wmax[kSelThreads / 64];
+    // Long candidate lists (one key per 64 stored rows): first cut the list down.  The keff-th largest of the per-thread
+    // maxima, T, is a lower bound of the keff-th largest key (keff threads each hold a key >= T), so only keys >= T can be
+    // selected - typically a few times keff of them.  Wave 0 finds T and then the answer among the survivors without a
+    // single workgroup barrier per round; the rounds below (two barriers each, 16 waves) remain the fallback when too many
+    // keys survive (ties in bulk).
+    __shared__ uint64_t surv[kSelThreads];
+    __shared__ unsigned int s_nsurv;
+    bool done = false;
+    if (nthr == kSelThreads && keff > 1 && keff <= 64) {
+        uint64_t tm = 0;
+        for_each_key([&](uint64_t key) { tm = key > tm ? key : tm; });
+        surv[tid] = tm;
+        if (tid == 0) s_nsurv = 0;
+        __syncthreads();
+        auto wave_max64 = [](uint64_t v) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), o, 64), lo = __shfl_xor((uint32_t)v, o, 64);
+                const uint64_t other = ((uint64_t)hi << 32) | lo;
+                v = other > v ? other : v;
+            }
+            return v;
+        };
+        constexpr int PER = kSelThreads / 64;          // values per lane of wave 0
+        if (tid < 64) {
+            uint64_t v[PER];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) v[j] = surv[j * 64 + tid];
+            uint64_t T = 0;
+            for (unsigned int it = 0; it < keff; ++it) {
+                uint64_t m = 0;
+#pragma unroll
+                for (int j = 0; j < PER; ++j) m = v[j] > m ? v[j] : m;
+                T = wave_max64(m);
+                if (m == T) {                      // unique keys: one lane, one slot (0 only when fewer than keff threads hold keys)
+#pragma unroll
+                    for (int j = 0; j < PER; ++j)
+                        if (v[j] == T) v[j] = 0;
+                }
+            }
+            if (tid == 0) wmax[0] = T;
+        }
+        __syncthreads();
+        const uint64_t T = wmax[0];
+        __syncthreads();                           // surv[] is reused below
+        if (T != 0) {
+            for_each_key([&](uint64_t key) {
+                if (key >= T) {
+                    const unsigned int slot = atomicAdd(&s_nsurv, 1u);
+                    if (slot < (unsigned int)kSelThreads) surv[slot] = key;
+                }
+            });
+        }
+        __syncthreads();
+        const unsigned int ns = s_nsurv;
+        if (T != 0 && ns <= (unsigned int)kSelThreads) {
+            if (tid < 64) {
+                uint64_t v[PER];
+#pragma unroll
+                for (int j = 0; j < PER; ++j) v[j] = (unsigned int)(j * 64 + tid) < ns ? surv[j * 64 + tid] : 0;
+                for (unsigned int it = 0; it < keff; ++it) {
+                    uint64_t m = 0;
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) m = v[j] > m ? v[j] : m;
+                    const uint64_t gm = wave_max64(m);
+                    if (tid == 0) sorted[it] = gm;
+                    if (m == gm) {
+#pragma unroll
+                        for (int j = 0; j < PER; ++j)
+                            if (v[j] == gm) v[j] = 0;
+                    }
+                }
+            }
+            done = true;                          // uniform: T and ns come from shared memory
+            __syncthreads();
+        }
+    }
+    if (done) {
+        // sorted[0 .. keff) is filled
+    } else if (cached && keff <= 64) {
         // Small k (the reference asks for 10..50): extract the maximum keff times.  Per round: 16 register compares, a
         // wave max by shuffles, one LDS word per wave, two barriers - a few hundred cycles, against radix passes whose LDS
         // histogram atomics all collide on one bin when the scores share their leading bits.
-        __shared__ uint64_t wmax[kSelThreads / 64];
         for (unsigned int it = 0; it < keff; ++it) {
             uint64_t m = 0;
 #pragma unroll
