@@ -82,6 +82,20 @@ __device__ __forceinline__ float act_fn(float x, int act) {
         const float e = __expf(-1.702f * x);
         return FAST ? x * __builtin_amdgcn_rcpf(1.0f + e) : x / (1.0f + e);
     }
+    if (FAST) {
+        // exact-GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside the bf16 / e4m3 output rounding):
+        // 2 transcendentals + 7 FMAs per element instead of the ~40-instruction erff expansion, which made the fc1 epilogue of
+        // the DINO tower (K = 384: six K steps per tile) three times as long as its K loop.
+        const float z = fabsf(x) * 0.70710678118654752f;
+        const float tt = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+        float p = fmaf(1.061405429f, tt, -1.453152027f);
+        p = fmaf(p, tt, 1.421413741f);
+        p = fmaf(p, tt, -0.284496736f);
+        p = fmaf(p, tt, 0.254829592f);
+        const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+        const float erf_abs = fmaf(-p * tt, e, 1.0f);
+        return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    }
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
 }
 
