@@ -1441,15 +1441,17 @@ __global__ __launch_bounds__(256, 5) void attention_mfma_short_kernel(const unsi
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) kf[ks][kt] = *reinterpret_cast<const uint4 *>(base + D + key * rs + ks * 32 + g * 8);
     }
-    // V -> LDS row-major (lane owns key `lane`: eight 16-B stores); the V^T fragments are read back with the transposing
+    // V -> LDS row-major (eight coalesced 1 KiB loads, eight 16-B stores per lane); the V^T fragments are read back with the transposing
     // ds_read_b64_tr_b16.  32-B segment s of a row sits at position s ^ ((row >> 1) & 3) (conflict-free transposed reads).
     {
-        const int key = min(lane, Tn - 1);
-        const uint4 *vp = reinterpret_cast<const uint4 *>(base + 2 * D + key * rs);
-        unsigned char *vrow = vt + lane * 128;
-        const int xr = (lane >> 1) & 3;
+        // coalesced: one load instruction = 8 key rows x 128 B (lane -> row 8 i + (lane >> 3), 16-B chunk lane & 7)
+        const int ch = lane & 7;
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) *reinterpret_cast<uint4 *>(vrow + ((((ch >> 1) ^ xr) << 5) | ((ch & 1) << 4))) = vp[ch];
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (lane >> 3), key = min(row, Tn - 1), xr = (row >> 1) & 3;
+            const uint4 v = *reinterpret_cast<const uint4 *>(base + 2 * D + key * rs + ch * 8);
+            *reinterpret_cast<uint4 *>(vt + row * 128 + ((((ch >> 1) ^ xr) << 5) | ((ch & 1) << 4))) = v;
+        }
     }
     unsigned offV[4];
     {
