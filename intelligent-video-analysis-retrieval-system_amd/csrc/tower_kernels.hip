@@ -1433,24 +1433,43 @@ __global__ __launch_bounds__(256, 5) void attention_mfma_short_kernel(const unsi
     const int64_t rs = 3 * (int64_t)D;
     const unsigned short *base = qkv + (int64_t)img * Tn * rs + h * 64;
 
-    // K fragments (A operand of S^T): key = 16*kt + c, dh = 32*ks + 8*g .. +7
+    // K and V rows of the head: eight coalesced loads each (one instruction = 8 key rows x 128 B; lane -> row 8 i + (lane >> 3),
+    // 16-B chunk lane & 7), all sixteen in flight together.  K goes through the wave's LDS region first (chunk ch of a row at
+    // position ch ^ (row & 7): conflict-free ds_read_b128 of the A fragments), then V takes the region over.
     uint4 kf[2][4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        const int key = min(kt * 16 + c, Tn - 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) kf[ks][kt] = *reinterpret_cast<const uint4 *>(base + D + key * rs + ks * 32 + g * 8);
-    }
-    // V -> LDS row-major (eight coalesced 1 KiB loads, eight 16-B stores per lane); the V^T fragments are read back with the transposing
-    // ds_read_b64_tr_b16.  32-B segment s of a row sits at position s ^ ((row >> 1) & 3) (conflict-free transposed reads).
     {
-        // coalesced: one load instruction = 8 key rows x 128 B (lane -> row 8 i + (lane >> 3), 16-B chunk lane & 7)
         const int ch = lane & 7;
+        uint4 kv[8], vv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int row = 8 * i + (lane >> 3), key = min(row, Tn - 1), xr = (row >> 1) & 3;
-            const uint4 v = *reinterpret_cast<const uint4 *>(base + 2 * D + key * rs + ch * 8);
-            *reinterpret_cast<uint4 *>(vt + row * 128 + ((((ch >> 1) ^ xr) << 5) | ((ch & 1) << 4))) = v;
+            const int key = min(8 * i + (lane >> 3), Tn - 1);
+            kv[i] = *reinterpret_cast<const uint4 *>(base + D + key * rs + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int key = min(8 * i + (lane >> 3), Tn - 1);
+            vv[i] = *reinterpret_cast<const uint4 *>(base + 2 * D + key * rs + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (lane >> 3);
+            *reinterpret_cast<uint4 *>(vt + row * 128 + ((ch ^ (row & 7)) << 4)) = kv[i];
+        }
+        // K fragments (A operand of S^T): key = 16*kt + c, dh = 32*ks + 8*g .. +7
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                kf[ks][kt] = *reinterpret_cast<const uint4 *>(vt + (kt * 16 + c) * 128 + (((4 * ks + g) ^ (c & 7)) << 4));
+        // V -> LDS row-major; the V^T fragments are read back with the transposing ds_read_b64_tr_b16.  32-B segment s of a row
+        // sits at position s ^ ((row >> 1) & 3) (conflict-free transposed reads).  Same wave, LDS in order: the K reads above
+        // have returned their data before these stores are issued (the compiler waits for kf before its first use or keeps the
+        // order; the explicit wait makes the dependence unconditional).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (lane >> 3), xr = (row >> 1) & 3;
+            *reinterpret_cast<uint4 *>(vt + row * 128 + ((((ch >> 1) ^ xr) << 5) | ((ch & 1) << 4))) = vv[i];
         }
     }
     unsigned offV[4];
