@@ -19,22 +19,6 @@ namespace {
 constexpr int kDedupMaxPer = 32;       // d <= 64 * 32
 constexpr int kDedupLds = 64 * 1024;   // two chunks
 
-// wave sum on the DPP / permlane paths (a few cycles per step) instead of six ds_bpermute round trips: the chain's critical
-// path per frame is two of these.  Every lane ends with the total.
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    auto dpp = [](float x, auto ctrl) {
-        return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), decltype(ctrl)::value, 0xf, 0xf, false));
-    };
-    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
-    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
-    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
-    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror: the 16 lanes of a row hold the row sum
-    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
 template <int PER>      // floats of a row per lane: d <= 64 * PER
 __global__ __launch_bounds__(256) void dedup_kernel(const float *__restrict__ emb, int n, int d, float threshold,
                                                     float *__restrict__ state, uint8_t *__restrict__ keep) {
@@ -66,7 +50,7 @@ __global__ __launch_bounds__(256) void dedup_kernel(const float *__restrict__ em
 #pragma unroll
             for (int j = 0; j < PER; ++j)
                 if (lane + 64 * j < d) prev_ss = fmaf(prev[j], prev[j], prev_ss);
-            prev_ss = wave_sum_dpp(prev_ss);
+            prev_ss = ivr_wave_sum(prev_ss);
         }
     }
     for (int c = 0; c < nchunks; ++c) {
@@ -88,8 +72,8 @@ __global__ __launch_bounds__(256) void dedup_kernel(const float *__restrict__ em
                         if (has_prev) dot = fmaf(cur[j], prev[j], dot);
                     }
                 }
-                dot = wave_sum_dpp(dot);
-                ss = wave_sum_dpp(ss);
+                dot = ivr_wave_sum(dot);
+                ss = ivr_wave_sum(ss);
                 bool uniq = true;
                 if (has_prev) {
                     // sklearn normalises each row (zero norm -> 1) and takes the dot product

@@ -91,13 +91,30 @@ __device__ __forceinline__ uint32_t ivr_pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// Wave-wide reductions on the DPP / permlane paths (a few cycles per step) instead of six ds_bpermute round trips through the
+// LDS pipe.  Butterfly over lane bits 0..3 inside a row of 16 (quad_perm, quad_perm, row_half_mirror, row_mirror), then
+// v_permlane16_swap / v_permlane32_swap across rows.  Every lane ends with the result.
+template <int CTRL>
+__device__ __forceinline__ float ivr_dpp(float x) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float ivr_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += ivr_dpp<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += ivr_dpp<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += ivr_dpp<0x141>(v);      // row_half_mirror
+    v += ivr_dpp<0x140>(v);      // row_mirror
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float ivr_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, ivr_dpp<0xB1>(v));
+    v = fmaxf(v, ivr_dpp<0x4E>(v));
+    v = fmaxf(v, ivr_dpp<0x141>(v));
+    v = fmaxf(v, ivr_dpp<0x140>(v));
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
