@@ -1566,7 +1566,7 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
             attr_done = true;
         }
         const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
-        ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 8);     // measured: narrow outputs want short groups
+        ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 4);     // measured (sweep 2..16): within 2 %, narrow outputs want short groups
         // the row-wide epilogue needs whole 64-column wave blocks (N % 64 == 0) and 16-byte aligned rows
         const bool bias_ok = !g.bias || reinterpret_cast<uintptr_t>(g.bias) % 16 == 0;
         if (EPI == EPI_STORE)
@@ -1632,7 +1632,7 @@ int launch_gemm8_t(const GemmArgs &g, hipStream_t s) {
     const int group_env = std::max(0, env_int("IVR_GEMM_GROUP_M", 0));
     GemmArgs ga = g;
     const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
-    ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 8);
+    ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 4);
     ga.wide_epi = 1;
     hipLaunchKernelGGL((gemm_big8_kernel<EPI, ACT, OUT8>), dim3(8 * ((MT + 7) / 8) * NT), dim3(512), DEEP_LDS, s, ga);
     IVR_LAUNCH_CHECK();
