@@ -128,3 +128,14 @@ def test_switch_off(monkeypatch):
     idx.add(X, normalize=True)
     has16, _ = _check(idx, idx.reconstruct_n(0, N), rng.standard_normal((10, d)).astype(np.float32), 10)
     assert not has16
+
+
+def test_randomised_cross_check_against_exact_scan():
+    """tools/fuzz_search.py for a few seconds: random d, N, nq, k and row distributions (clusters, duplicates, scaled, sparse,
+    zero rows); candidate-scan result must equal the exact float32 scan's bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_search.py"), "8", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
