@@ -18,6 +18,7 @@ from ivr_amd.index import FlatIPIndex  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0, draws, fast_hits, redone_total, bad = time.time(), 0, 0, 0, 0
+last_print = t0
 while time.time() - t0 < budget:
     d = int(rng.choice([16, 48, 96, 128, 384, 512, 768, 1000]))
     N = int(rng.integers(20_000, 400_000))
@@ -57,5 +58,8 @@ while time.time() - t0 < budget:
         bad += 1
         print(f"MISMATCH d={d} N={N} nq={nq} k={k} kind={kind} normalize={normalize}: ids differ at {(Ia != Ib).nonzero()[:4].tolist()}")
     del a, b, X, Q
+    if time.time() - last_print > 30:
+        last_print = time.time()
+        print(f"  ... {draws} draws, {bad} mismatches after {last_print - t0:.0f} s", flush=True)
 print(f"fuzz: {draws} draws, {bad} mismatches; queries redone exactly in the last chunks: {redone_total}")
 sys.exit(1 if bad else 0)
