@@ -622,11 +622,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
 
     u32x4 xa0[8], wa0[4], xa1[8], wa1[4];
     u32x4 *x0lo = xa0, *x0hi = xa0 + 4, *x1lo = xa1, *x1hi = xa1 + 4;
-    // prologue: stage 0 whole, then X(1), W(1), X(2) in that order (the order the counted waits below rely on)
+    // prologue: stage 0, then X(1), W(1), X(2) in that order (the order the counted waits below rely on), all issued before
+    // the first wait: every slot is free at the start of a tile, and stage 1 then has the whole latency of stage 0 as a head start
 #pragma unroll
     for (int j = 0; j < 8; ++j) piece(0, 0, j);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    IVR_STAMP(1)
     if (KT > 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) piece(1, 1, j);
@@ -635,6 +634,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) piece(2, 2, j);
     }
+    if (KT > 2) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    else if (KT > 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    IVR_STAMP(1)
     IVR_RD4(wa0, foW[0], 0)
     IVR_RD4(x0lo, foX[0], 0)
     IVR_RD4(x0hi, foX[0], 8192)
@@ -870,15 +873,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big8_kernel(GemmArgs g) {
     asm volatile("" : "+v"(acc[NT][LO]), "+v"(acc[NT][LO + 1]), "+v"(acc[NT][LO + 2]), "+v"(acc[NT][LO + 3]));  \
     __builtin_amdgcn_sched_barrier(0);
 
+    // stage 0, X(1), W(1), then the first half of X(2), all before the first wait (ten younger pieces may stay in flight);
+    // every later window is W(s+2) x 4, X(s+3) x 4 with the last two X pieces issued early in the following stage, so at every
+    // mid-stage barrier the four youngest pieces are X two stages ahead
 #pragma unroll
     for (int j = 0; j < 8; ++j) piece(0, 0, j, true);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    // X(1), W(1), then the first half of X(2); every later window is W(s+2) x 4, X(s+3) x 4 with the last two X pieces
-    // issued early in the following stage, so at every mid-stage barrier the four youngest pieces are X two stages ahead
 #pragma unroll
     for (int j = 0; j < 8; ++j) piece(1, 1, j, KT > 1);
     piece(2, 2, 0, KT > 2);
     piece(2, 2, 1, KT > 2);
+    asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 4; ++i) xf[i] = frag(offX, i);
 #pragma unroll
