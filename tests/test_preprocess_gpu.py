@@ -49,6 +49,22 @@ def test_more_geometry_vs_oracle(mode, h, w):
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
 
 
+def test_random_sizes_modes_and_output_sizes_vs_oracle():
+    """24 seeded draws of input size (17..900 px per side), geometry mode, BGR flag and output size: float32 output bit-exact."""
+    from ivr_amd.preprocess import preprocess_frames
+    rng = np.random.default_rng(20251005)
+    for i in range(24):
+        h, w = int(rng.integers(17, 900)), int(rng.integers(17, 900))
+        mode = str(rng.choice(["stretch", "shortest_edge_crop", "letterbox"]))
+        bgr, size = bool(rng.integers(2)), int(rng.choice([112, 224, 336]))
+        frames = synth_frames(1000 + i, 2, h, w) if i % 2 else smooth_frames(1000 + i, 2, h, w)
+        out = preprocess_frames(frames, mode, C.CLIP_MEAN, C.CLIP_STD, bgr=bgr, size=size, out_dtype=torch.float32)      # NCHW
+        ref = P.preprocess(frames, mode, C.CLIP_MEAN, C.CLIP_STD, bgr=bgr, size=size)
+        got = out.cpu().numpy()
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (i, h, w, mode, bgr, size)
+
+
 def test_bilinear_filter_vs_oracle():
     from ivr_amd.preprocess import preprocess_frames
     frames = synth_frames(77, 2, 300, 400)
