@@ -32,7 +32,7 @@ template <typename T>
 struct El;
 template <>
 struct El<unsigned short> {
-    static constexpr int per16 = 8;   // elements per 16 bytes (attention_kernel chunking)
+    [[maybe_unused]] static constexpr int per16 = 8;   // elements per 16 bytes (attention_kernel chunking)
     static __device__ __forceinline__ void unpack(const uint4 &u, float (&f)[8]) {
         f[0] = __uint_as_float(u.x << 16);
         f[1] = __uint_as_float(u.x & 0xffff0000u);
