@@ -20,6 +20,10 @@
 #include "tower.h"
 #include "tower_kernels.h"
 
+#include <map>
+#include <mutex>
+#include <type_traits>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -1226,8 +1230,8 @@ __device__ __forceinline__ float quad_sum(float x) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-template <int QC, typename TOut>
-__global__ __launch_bounds__(384, 3) void attention_head_kernel(const unsigned short *__restrict__ qkv, TOut *__restrict__ att,
+template <int QC, typename TOut, int MINW = 3>
+__global__ __launch_bounds__(384, MINW) void attention_head_kernel(const unsigned short *__restrict__ qkv, TOut *__restrict__ att,
                                                                 int Tn, int D, int heads, int causal, int nsplit, int Tp) {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1708,27 +1712,70 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
         const int head_env = env_int("IVR_ATTN_HEAD", 1);     // 0: force the generic flash kernel (A/B, tests)
         if (head_env && 2 * Tp * 128 <= 160 * 1024 && (int64_t)T * 3 * D * 2 < 0x7fffffff) {
             // head-resident kernel: K and V of a head in LDS, QC query tiles of 16 per wave, at most 6 waves per workgroup
-            constexpr int QC = 3;
             const int ntiles = (T + 15) / 16;
-            const int nsplit = ivr_ceil_div(ntiles, 6 * QC);
-            const int tps = ivr_ceil_div(ntiles, nsplit), nw = ivr_ceil_div(tps, QC);
-            const int lds = 2 * Tp * 128;
-            static int attr_lds = 0;
-            if (lds > attr_lds) {
-                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_head_kernel<QC, unsigned short>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_head_kernel<QC, unsigned char>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                attr_lds = lds;
+            auto go = [&](auto qc_c, auto minw_c) -> int {
+                constexpr int QC = decltype(qc_c)::value, MINW = decltype(minw_c)::value;
+                const int nsplit = ivr_ceil_div(ntiles, 6 * QC);
+                const int tps = ivr_ceil_div(ntiles, nsplit), nw = ivr_ceil_div(tps, QC);
+                const int lds = 2 * Tp * 128;
+                static int attr_lds = 0;
+                if (lds > attr_lds) {
+                    IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_head_kernel<QC, unsigned short, MINW>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                    IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_head_kernel<QC, unsigned char, MINW>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                    attr_lds = lds;
+                }
+                const dim3 grid((unsigned)((int64_t)n * heads * nsplit)), block(64 * nw);
+                if (out_fp8)
+                    hipLaunchKernelGGL((attention_head_kernel<QC, unsigned char, MINW>), grid, block, lds, s, (const unsigned short *)qkv,
+                                       (unsigned char *)att, T, D, heads, causal, nsplit, Tp);
+                else
+                    hipLaunchKernelGGL((attention_head_kernel<QC, unsigned short, MINW>), grid, block, lds, s, (const unsigned short *)qkv,
+                                       (unsigned short *)att, T, D, heads, causal, nsplit, Tp);
+                IVR_LAUNCH_CHECK();
+                return IVR_OK;
+            };
+            auto run = [&](int qc) -> int {
+                return qc == 4 ? go(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{})
+                               : go(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
+            };
+            // Three or four query tiles per wave: which is faster depends on how the tile count splits into waves and SIMDs
+            // (tools/bench_attention.py: 13 tiles 1.6x in favour of four, 17 tiles 1.2x in favour of three), so the first
+            // call with a given shape times both once (the kernel is idempotent) and keeps the winner.  Never while the stream
+            // is being captured into a graph: that call runs the default and leaves the choice open.
+            const int forced = env_int("IVR_ATTN_QC", 0);
+            if (forced == 3 || forced == 4) return run(forced);
+            static std::mutex tune_mu;
+            static std::map<uint64_t, int> tuned;
+            const uint64_t key = ((uint64_t)T << 32) | ((uint64_t)heads << 8) | ((uint64_t)(causal != 0) << 1) | (uint64_t)out_fp8;
+            {
+                std::lock_guard<std::mutex> lk(tune_mu);
+                auto it = tuned.find(key);
+                if (it != tuned.end()) return run(it->second);
             }
-            const dim3 grid((unsigned)((int64_t)n * heads * nsplit)), block(64 * nw);
-            if (out_fp8)
-                hipLaunchKernelGGL((attention_head_kernel<QC, unsigned char>), grid, block, lds, s, (const unsigned short *)qkv,
-                                   (unsigned char *)att, T, D, heads, causal, nsplit, Tp);
-            else
-                hipLaunchKernelGGL((attention_head_kernel<QC, unsigned short>), grid, block, lds, s, (const unsigned short *)qkv,
-                                   (unsigned short *)att, T, D, heads, causal, nsplit, Tp);
-            IVR_LAUNCH_CHECK();
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(s, &cap);
+            if (cap != hipStreamCaptureStatusNone || n * heads < 512) return run(3);       // too small to time meaningfully
+            hipEvent_t e[3];
+            for (auto &ev : e) IVR_HIP(hipEventCreate(&ev));
+            int rc = run(3);                                  // warm-up (function attributes, caches)
+            IVR_HIP(hipEventRecord(e[0], s));
+            if (rc == IVR_OK) rc = run(3);
+            IVR_HIP(hipEventRecord(e[1], s));
+            if (rc == IVR_OK) rc = run(4);
+            if (rc == IVR_OK) rc = run(4);
+            IVR_HIP(hipEventRecord(e[2], s));
+            IVR_HIP(hipEventSynchronize(e[2]));
+            float t3 = 0.f, t44 = 0.f;
+            IVR_HIP(hipEventElapsedTime(&t3, e[0], e[1]));
+            IVR_HIP(hipEventElapsedTime(&t44, e[1], e[2]));   // two launches of the four-tile variant (the first one warms it up)
+            for (auto &ev : e) (void)hipEventDestroy(ev);
+            if (rc != IVR_OK) return rc;
+            {
+                std::lock_guard<std::mutex> lk(tune_mu);
+                tuned[key] = 0.5f * t44 < t3 ? 4 : 3;
+            }
             return IVR_OK;
         }
         IVR_REQUIRE(!out_fp8, "attention: T=%d too long for the e4m3-output kernels", T);
