@@ -1737,15 +1737,16 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
                 return IVR_OK;
             };
             auto run = [&](int qc) -> int {
-                return qc == 4 ? go(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{})
-                               : go(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
+                return qc == 5   ? go(std::integral_constant<int, 5>{}, std::integral_constant<int, 2>{})
+                       : qc == 4 ? go(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{})
+                                 : go(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
             };
-            // Three or four query tiles per wave: which is faster depends on how the tile count splits into waves and SIMDs
+            // Three, four or five query tiles per wave: which is faster depends on how the tile count splits into waves and SIMDs
             // (tools/bench_attention.py: 13 tiles 1.6x in favour of four, 17 tiles 1.2x in favour of three), so the first
             // call with a given shape times both once (the kernel is idempotent) and keeps the winner.  Never while the stream
             // is being captured into a graph: that call runs the default and leaves the choice open.
             const int forced = env_int("IVR_ATTN_QC", 0);
-            if (forced == 3 || forced == 4) return run(forced);
+            if (forced >= 3 && forced <= 5) return run(forced);
             static std::mutex tune_mu;
             static std::map<uint64_t, int> tuned;
             const uint64_t key = ((uint64_t)T << 32) | ((uint64_t)heads << 8) | ((uint64_t)(causal != 0) << 1) | (uint64_t)out_fp8;
@@ -1757,26 +1758,30 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(s, &cap);
             if (cap != hipStreamCaptureStatusNone || n * heads < 512) return run(3);       // too small to time meaningfully
-            hipEvent_t e[3];
+            hipEvent_t e[4];
             for (auto &ev : e) IVR_HIP(hipEventCreate(&ev));
-            int rc = run(3);                                  // warm-up (function attributes, caches)
-            IVR_HIP(hipEventRecord(e[0], s));
-            if (rc == IVR_OK) rc = run(3);
-            IVR_HIP(hipEventRecord(e[1], s));
-            if (rc == IVR_OK) rc = run(4);
-            if (rc == IVR_OK) rc = run(4);
-            IVR_HIP(hipEventRecord(e[2], s));
-            IVR_HIP(hipEventSynchronize(e[2]));
-            float t3 = 0.f, t44 = 0.f;
-            IVR_HIP(hipEventElapsedTime(&t3, e[0], e[1]));
-            IVR_HIP(hipEventElapsedTime(&t44, e[1], e[2]));   // two launches of the four-tile variant (the first one warms it up)
+            int rc = IVR_OK, best = 3;
+            float best_ms = 0.f;
+            for (int qc = 3; qc <= 5 && rc == IVR_OK; ++qc) {
+                rc = run(qc);                                 // warm-up (function attributes, caches)
+                IVR_HIP(hipEventRecord(e[0], s));
+                if (rc == IVR_OK) rc = run(qc);
+                IVR_HIP(hipEventRecord(e[1], s));
+                IVR_HIP(hipEventSynchronize(e[1]));
+                float ms = 0.f;
+                IVR_HIP(hipEventElapsedTime(&ms, e[0], e[1]));
+                if (qc == 3 || ms < best_ms) {
+                    best = qc;
+                    best_ms = ms;
+                }
+            }
             for (auto &ev : e) (void)hipEventDestroy(ev);
             if (rc != IVR_OK) return rc;
             {
                 std::lock_guard<std::mutex> lk(tune_mu);
-                tuned[key] = 0.5f * t44 < t3 ? 4 : 3;
+                tuned[key] = best;
             }
-            return IVR_OK;
+            return run(best);                                 // the buffer holds the last candidate's (identical) result anyway
         }
         IVR_REQUIRE(!out_fp8, "attention: T=%d too long for the e4m3-output kernels", T);
         const int nqb = (T + 63) / 64;

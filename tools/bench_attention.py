@@ -19,7 +19,7 @@ for grid, patch in ((8, 4), (10, 8), (12, 4), (14, 8), (16, 4), (20, 4), (24, 4)
     tw = Tower(cfg, make_weights(cfg, 1), max_batch=n)
     frames = torch.randint(0, 256, (n, cfg.image, cfg.image, 3), device="cuda", dtype=torch.uint8)
     res = []
-    for qc in ("3", "4"):
+    for qc in ("3", "4", "5"):
         os.environ["IVR_ATTN_QC"] = qc
         for _ in range(2):
             tw.encode_frames(frames)
@@ -32,4 +32,4 @@ for grid, patch in ((8, 4), (10, 8), (12, 4), (14, 8), (16, 4), (20, 4), (24, 4)
         _ffi.profile_enable(False)
         p = _ffi.profile_read()["attention"]
         res.append(p["ms"] / p["launches"])
-    print(f"T={T:4d} tiles={-(-T // 16):3d} n={n:5d}: QC=3 {res[0]:7.3f} ms  QC=4 {res[1]:7.3f} ms  -> {'4' if res[1] < res[0] else '3'} ({res[0] / res[1]:.2f}x)")
+    print(f"T={T:4d} tiles={-(-T // 16):3d} n={n:5d}: QC=3 {res[0]:7.3f} ms  QC=4 {res[1]:7.3f} ms  QC=5 {res[2]:7.3f} ms  -> {3 + res.index(min(res))}")
