@@ -10,7 +10,10 @@ A "step" is one pass of the whole path over one batch, inputs already resident i
 value = frames embedded per second by the whole job (every frame also pays its share of the search);
 pairs_per_s = query x index-row cosines per second of the search part alone (HIP events), also reported.
 
-python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU.  Started from a plain shell the script launches `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...` itself as a child process and relays rank 0's JSON line;
+started under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 """
 import argparse
 import json
@@ -68,6 +71,60 @@ def cpu_baseline(cfg, weights, frames_u8, index_rows, queries, k, budget_s=20.0)
             "pairs_per_s": len(index_rows) * len(queries) / t_search, "threads": torch.get_num_threads(), "emb_dim": int(emb.shape[1])}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(n_ranks, script, script_args, port=None):
+    """The command `python bench.py --gpus N` turns itself into when it was started from a plain shell: one rank per
+    GPU under torch.distributed.run, rendezvous on 127.0.0.1 (replaces the reference's hand-rolled peer fan-out,
+    system.py:1715-1757 / api.py:877-925, by one launcher + one collective)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()), script, *script_args]
+
+
+def self_launch(n_ranks, script, script_args, env=None, visible_gpus=None):
+    """Start the N ranks as a CHILD process (never exec: nothing in this process has touched the GPU yet, and the
+    children are ordinary processes), relay rank 0's JSON line to stdout and return the launcher's exit code.
+    With fewer visible GPUs than ranks the ranks share devices and rendezvous over gloo (rehearsal of the
+    multi-rank control flow on a smaller box); with N GPUs visible the backend stays nccl (= RCCL over xGMI)."""
+    import subprocess
+    env = dict(os.environ if env is None else env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if visible_gpus is None:
+        visible_gpus = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    if visible_gpus < n_ranks and "IVR_DIST_BACKEND" not in env:
+        env["IVR_DIST_BACKEND"] = "gloo"
+        print(f"bench.py: {visible_gpus} GPU(s) visible for {n_ranks} ranks - ranks share devices, backend gloo (rehearsal)",
+              file=sys.stderr)
+    cmd = launcher_command(n_ranks, script, script_args)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and s.endswith("}"):
+            try:
+                json.loads(s)
+                line = s
+            except ValueError:
+                pass
+    other = [ln for ln in proc.stdout.splitlines() if ln.strip() != line]
+    if other:
+        print("\n".join(other), file=sys.stderr)
+    if line is not None:
+        print(line)
+        sys.stdout.flush()
+    elif proc.returncode == 0:
+        print("bench.py: the ranks finished without printing a JSON line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,10 +145,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started from a plain shell: become the launcher (before anything initialises the GPU in this process)
+        raise SystemExit(self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
