@@ -18,8 +18,12 @@
  *  - Every function returns IVR_OK (0) or a negative ivr_status and never throws
  *    or aborts; ivr_last_error() returns the calling thread's last message.
  *  - Handles may be used from several host threads (the reference calls
- *    encode_images from a 4-thread pool, unified_index.py:773): calls on one handle
- *    are serialised by a per-handle mutex, distinct handles are independent.
+ *    encode_images from a 4-thread pool, unified_index.py:773): the host side of calls
+ *    on one handle is serialised by a per-handle mutex, distinct handles are independent.
+ *    A tower / index handle owns device workspaces (activations, search candidates), so
+ *    all calls on ONE handle must be enqueued on ONE stream at a time: to move a handle
+ *    to another stream, make the new stream wait for the old one first.  ivr_preprocess
+ *    keeps its scratch per stream and may be called concurrently on different streams.
  */
 #ifndef IVR_API_H
 #define IVR_API_H
@@ -31,7 +35,7 @@
 extern "C" {
 #endif
 
-#define IVR_API_VERSION 1
+#define IVR_API_VERSION 2
 #define IVR_MAX_K 2048          /* reference: k=50 default, SearchOptions.limit <= 1000 (system.py:91) */
 
 typedef enum ivr_status {
@@ -86,7 +90,8 @@ int ivr_preprocess(ivr_ctx *ctx, const uint8_t *src /*DEV*/, int n, int h, int w
                    const float mean[3] /*HOST*/, const float std[3] /*HOST*/, int out_size, int patch,
                    void *dst /*DEV*/, ivr_stream stream);
 /* bytes of DEV scratch ivr_preprocess needs for (n,h,w,flags); 0 for identity geometry.  The scratch
- * lives in the context and grows on demand (outside of stream capture). */
+ * lives in the context, one block per stream, and grows on demand (outside of stream capture); outgrown
+ * blocks stay allocated until ivr_destroy because kernels in flight or a captured graph may still use them. */
 int64_t ivr_preprocess_scratch_bytes(int n, int h, int w, int flags, int out_size);
 
 /* ---- E1 / E2 / E3 + N1: encoder towers --------------------------------------------------------
@@ -100,10 +105,12 @@ enum { IVR_KIND_VISION = 0, IVR_KIND_TEXT = 1 };
 enum {
     IVR_COMPUTE_BF16 = 0,
     IVR_COMPUTE_F32 = 1, /* verification mode: f32 MFMA, f32 activations */
-    IVR_COMPUTE_FP8 = 2  /* BASELINE config 5: the four GEMMs of every block on the CDNA4 fp8 MFMA (e4m3 operands, per-output-
-                          * channel weight scales, f32 accumulate); patch embedding, attention products, LN, residual stream and
-                          * projection as in the bf16 mode */
+    IVR_COMPUTE_FP8 = 2  /* BASELINE config 5: the linear sites of every block named by desc.fp8_sites on the CDNA4 fp8 MFMA
+                          * (e4m3 operands, per-output-channel weight scales, f32 accumulate), the other sites on the bf16 MFMA;
+                          * patch embedding, attention products, LN, residual stream and projection as in the bf16 mode */
 };
+/* the four linear sites of a transformer block (modeling_clip.py:259-277 q/k/v/out_proj, :338-350 fc1/fc2) */
+enum { IVR_FP8_SITE_QKV = 1, IVR_FP8_SITE_ATTN_OUT = 2, IVR_FP8_SITE_FC1 = 4, IVR_FP8_SITE_FC2 = 8, IVR_FP8_SITE_ALL = 15 };
 
 typedef struct ivr_tower_desc {
     int kind, width, layers, heads, mlp, tokens, out_dim, act, pool;
@@ -111,6 +118,11 @@ typedef struct ivr_tower_desc {
     int vocab, eos_id, causal;               /* text */
     int compute;                             /* IVR_COMPUTE_* */
     float ln_eps;
+    /* IVR_COMPUTE_FP8 only.  fp8_sites: mask of IVR_FP8_SITE_* that run in e4m3 (0 = all four).  fp8_mlp_cls_bf16 = 1:
+     * the rows of token 0 (CLS, the only row the vision pooling reads) go through fc1 / fc2 in bf16 on a side path
+     * (n rows per launch instead of n*tokens), the e4m3 GEMMs leave those residual rows alone.  Which assignment stays
+     * inside which tolerance: DESIGN.md section 4, profiles/r02_fp8_error_budget.json. */
+    int fp8_sites, fp8_mlp_cls_bf16;
 } ivr_tower_desc;
 
 int ivr_tower_create(ivr_ctx *ctx, const ivr_tower_desc *desc, ivr_tower **out);

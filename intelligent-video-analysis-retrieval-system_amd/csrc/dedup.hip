@@ -143,11 +143,7 @@ extern "C" int ivr_dedup_keep_mask(ivr_ctx *ctx, const float *emb, int n, int d,
     IVR_HIP(hipSetDevice(ctx->device));
     auto launch = [&](auto per) -> int {
         constexpr int PER = decltype(per)::value;
-        static bool attr_done = false;
-        if (!attr_done) {
-            IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dedup_kernel<PER>), hipFuncAttributeMaxDynamicSharedMemorySize, kDedupLds));
-            attr_done = true;
-        }
+        if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(dedup_kernel<PER>), kDedupLds)) return rc;
         hipLaunchKernelGGL(dedup_kernel<PER>, dim3(1), dim3(256), kDedupLds, (hipStream_t)stream, emb, n, d, threshold, state, keep);
         return IVR_OK;
     };

@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/ivr_api.h"
 
@@ -17,9 +18,17 @@ struct ivr_ctx {
     int64_t hbm_bytes = 0;
     char arch[64] = {0};
     std::mutex mu;
-    // grow-only device scratch (preprocess intermediates, merge workspaces)
-    void *scratch = nullptr;
-    size_t scratch_bytes = 0;
+    // Device scratch (preprocess intermediates): ONE grow-only block per stream.  Work of one stream is ordered, so calls
+    // on the same stream may share a block; calls on different streams (the reference drives encode_images from a 4-thread
+    // pool, unified_index.py:773) never do.  An outgrown block may still be referenced by kernels in flight or by a captured
+    // HIP graph (StreamingSession), so it is only retired here and freed in ivr_destroy.
+    struct Scratch {
+        void *ptr = nullptr;
+        size_t bytes = 0;
+    };
+    std::map<hipStream_t, Scratch> scratch;
+    std::vector<void *> retired;
+    std::mutex enqueue_mu;                 // held across a whole multi-launch enqueue that uses a scratch block
     std::map<std::string, float *> luts;   // preprocess value tables, keyed by the mean/std bytes
 };
 
@@ -41,7 +50,10 @@ int ivr_fail(int code, const char *fmt, ...);
 
 #define IVR_LAUNCH_CHECK() IVR_HIP(hipGetLastError())
 
-int ivr_ctx_scratch(ivr_ctx *ctx, size_t bytes, void **out);
+int ivr_ctx_scratch(ivr_ctx *ctx, hipStream_t stream, size_t bytes, void **out);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel) and size: the opt-in is per device, and towers /
+// indexes of several devices may live in one process
+int ivr_func_max_lds(const void *fn, int bytes);
 
 // Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline figures).
 // `work` is the launch's algorithmic work: bytes for HBM-bound kernels, FLOP for MFMA-bound ones.

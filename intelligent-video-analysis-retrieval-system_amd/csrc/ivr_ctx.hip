@@ -1,6 +1,7 @@
 // Context, error slot and scratch management for libivr_hip.so.
 #include "ivr_common.h"
 
+#include <algorithm>
 #include <array>
 #include <atomic>
 #include <cstring>
@@ -21,17 +22,38 @@ int ivr_fail(int code, const char *fmt, ...) {
     return code;
 }
 
-int ivr_ctx_scratch(ivr_ctx *ctx, size_t bytes, void **out) {
+int ivr_ctx_scratch(ivr_ctx *ctx, hipStream_t stream, size_t bytes, void **out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (bytes > ctx->scratch_bytes) {
-        if (ctx->scratch) IVR_HIP(hipFree(ctx->scratch));
-        ctx->scratch = nullptr;
-        ctx->scratch_bytes = 0;
-        size_t want = (size_t)ivr_round_up((int64_t)bytes, 1 << 20);
-        IVR_HIP(hipMalloc(&ctx->scratch, want));
-        ctx->scratch_bytes = want;
+    ivr_ctx::Scratch &b = ctx->scratch[stream];
+    if (bytes > b.bytes) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        if (cap != hipStreamCaptureStatusNone)
+            return ivr_fail(IVR_ERR_STATE, "scratch of %zu bytes for a stream under graph capture: run the same call once on THIS stream "
+                                           "before capturing (the block is per stream and cannot be allocated during capture)", bytes);
+        // at least 1.5x the old block, so the retired list stays logarithmic in the final size
+        const size_t want = (size_t)ivr_round_up((int64_t)std::max(bytes, b.bytes + b.bytes / 2), 1 << 20);
+        void *p = nullptr;
+        IVR_HIP(hipMalloc(&p, want));
+        if (b.ptr) ctx->retired.push_back(b.ptr);
+        b.ptr = p;
+        b.bytes = want;
     }
-    *out = ctx->scratch;
+    *out = b.ptr;
+    return IVR_OK;
+}
+
+int ivr_func_max_lds(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, int> done;
+    int dev = 0;
+    IVR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    int &have = done[{dev, fn}];
+    if (bytes > have) {
+        IVR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        have = bytes;
+    }
     return IVR_OK;
 }
 
@@ -152,7 +174,10 @@ int ivr_init(int device, ivr_ctx **out) {
 
 int ivr_destroy(ivr_ctx *ctx) {
     if (!ctx) return IVR_OK;
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (auto &kv : ctx->scratch)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    for (void *p : ctx->retired) (void)hipFree(p);
+    for (auto &kv : ctx->luts) (void)hipFree(kv.second);
     delete ctx;
     return IVR_OK;
 }

@@ -383,12 +383,16 @@ int ivr_preprocess(ivr_ctx *ctx, const uint8_t *src, int n, int h, int w, int fl
     // ---- geometry -> uint8 [n,S,S,3]
     const uint8_t *canvas = src;
     const bool trivial = h == S && w == S;
+    // the resample / emit launches of one call go out back to back: two host threads on the same stream must not interleave
+    // them on the stream's scratch block (distinct streams have distinct blocks)
+    std::unique_lock<std::mutex> enqueue(ctx->enqueue_mu, std::defer_lock);
     if (!trivial) {
+        enqueue.lock();
         const Plan *p = nullptr;
         int rc = get_plan(ctx->device, h, w, mode, (flags & IVR_PP_BILINEAR) != 0, S, &p);
         if (rc != IVR_OK) return rc;
         void *scratch = nullptr;
-        rc = ivr_ctx_scratch(ctx, (size_t)ivr_preprocess_scratch_bytes(n, h, w, flags, S), &scratch);
+        rc = ivr_ctx_scratch(ctx, s, (size_t)ivr_preprocess_scratch_bytes(n, h, w, flags, S), &scratch);
         if (rc != IVR_OK) return rc;
         uint8_t *cv = reinterpret_cast<uint8_t *>(scratch);
         uint8_t *tmp = cv + ivr_round_up((int64_t)n * S * S * 3, 256);

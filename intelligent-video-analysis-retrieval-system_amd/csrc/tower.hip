@@ -26,6 +26,10 @@ int ivr_tower_create(ivr_ctx *ctx, const ivr_tower_desc *d, ivr_tower **out) {
                 "ivr_tower_create: compute=%d", d->compute);
     IVR_REQUIRE(d->compute != IVR_COMPUTE_FP8 || (d->width % 128 == 0 && d->mlp % 128 == 0),
                 "ivr_tower_create: the fp8 mode needs width and mlp to be multiples of 128 (width=%d mlp=%d)", d->width, d->mlp);
+    IVR_REQUIRE(d->fp8_sites >= 0 && d->fp8_sites <= IVR_FP8_SITE_ALL && (d->fp8_mlp_cls_bf16 == 0 || d->fp8_mlp_cls_bf16 == 1),
+                "ivr_tower_create: fp8_sites=%d fp8_mlp_cls_bf16=%d", d->fp8_sites, d->fp8_mlp_cls_bf16);
+    IVR_REQUIRE(d->compute == IVR_COMPUTE_FP8 || (d->fp8_sites == 0 && d->fp8_mlp_cls_bf16 == 0),
+                "ivr_tower_create: fp8_sites / fp8_mlp_cls_bf16 only apply to IVR_COMPUTE_FP8");
     if (d->kind == IVR_KIND_VISION) {
         IVR_REQUIRE(d->patch >= 1 && d->image % d->patch == 0, "ivr_tower_create: patch=%d image=%d", d->patch, d->image);
         const int g = d->image / d->patch;
@@ -40,6 +44,11 @@ int ivr_tower_create(ivr_ctx *ctx, const ivr_tower_desc *d, ivr_tower **out) {
     ivr_tower *t = new ivr_tower();
     t->ctx = ctx;
     t->d = *d;
+    if (d->compute == IVR_COMPUTE_FP8) {
+        t->sites = d->fp8_sites ? d->fp8_sites : IVR_FP8_SITE_ALL;
+        // the side path only exists where the pooling reads token 0 and at least one MLP site is e4m3
+        t->mlp_cls = d->fp8_mlp_cls_bf16 && d->kind == IVR_KIND_VISION && (t->sites & (IVR_FP8_SITE_FC1 | IVR_FP8_SITE_FC2));
+    }
     *out = t;
     return IVR_OK;
 }
@@ -152,7 +161,7 @@ unsigned char host_e4m3(float f) {
     return (unsigned char)(sign | ((E + 7) << 3) | mant);
 }
 
-// fp8 mode: weight [N, K] -> e4m3 bytes with one scale per output row (absmax / 448), stored as `name` and `name`_s
+// fp8 mode: weight [N, K] -> e4m3 bytes with one scale per output row (absmax / 448), stored as `name`@e4m3 and `name`@scale
 int upload_fp8(ivr_tower *t, const std::string &name, const float *host, int64_t N, int64_t K) {
     std::vector<unsigned char> q((size_t)(N * K));
     std::vector<float> sc((size_t)N);
@@ -168,18 +177,13 @@ int upload_fp8(ivr_tower *t, const std::string &name, const float *host, int64_t
     tt.bytes_per = 1;
     IVR_HIP(hipMalloc(&tt.ptr, q.size()));
     IVR_HIP(hipMemcpy(tt.ptr, q.data(), q.size(), hipMemcpyHostToDevice));
-    auto it = t->w.find(name);
-    if (it != t->w.end()) {
-        (void)hipFree(it->second.ptr);
-        t->w.erase(it);
-    }
-    t->w[name] = tt;
+    t->w[name + "@e4m3"] = tt;
     TowerTensor ts;
     ts.count = N;
     ts.bytes_per = 4;
     IVR_HIP(hipMalloc(&ts.ptr, (size_t)N * 4));
     IVR_HIP(hipMemcpy(ts.ptr, sc.data(), (size_t)N * 4, hipMemcpyHostToDevice));
-    t->w[name + "_s"] = ts;
+    t->w[name + "@scale"] = ts;
     return IVR_OK;
 }
 
@@ -189,28 +193,32 @@ T *wptr(ivr_tower *t, const std::string &name) {
     return it == t->w.end() ? nullptr : reinterpret_cast<T *>(it->second.ptr);
 }
 
-// y = x W^T through the mode's GEMM: bf16 / f32 operands, or e4m3 operands with the weight's per-row scale
-int layer_gemm(ivr_tower *t, int epi, GemmArgs &g, const std::string &wname, hipStream_t s) {
-    g.W = wptr<void>(t, wname);
-    if (t->d.compute == IVR_COMPUTE_FP8) {
-        g.colscale = wptr<float>(t, wname + "_s");
+// y = x W^T of one linear site: e4m3 operands with the weight's per-row scale when the site is in the fp8 mask, else bf16 / f32
+int layer_gemm(ivr_tower *t, bool site_fp8, int epi, GemmArgs &g, const std::string &wname, hipStream_t s) {
+    if (site_fp8) {
+        g.W = wptr<void>(t, wname + "@e4m3");
+        g.colscale = wptr<float>(t, wname + "@scale");
         return ivr_launch_gemm_fp8(epi, g, s);
     }
+    g.W = wptr<void>(t, wname);
     return ivr_launch_gemm(t->d.compute == IVR_COMPUTE_F32, epi, g, s);
 }
 
 // one transformer stack over `rows` = n*T residual rows already in t->resid
 int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
     const ivr_tower_desc &d = t->d;
-    const bool f32 = d.compute == IVR_COMPUTE_F32, fp8 = d.compute == IVR_COMPUTE_FP8;
-    const int act_kind = f32 ? OUT_F32 : fp8 ? OUT_FP8 : OUT_BF16;     // dtype of the GEMM A operands (LN / attention / MLP hidden)
+    const bool f32 = d.compute == IVR_COMPUTE_F32;
+    const bool q8 = t->sites & IVR_FP8_SITE_QKV, o8 = t->sites & IVR_FP8_SITE_ATTN_OUT, f18 = t->sites & IVR_FP8_SITE_FC1,
+               f28 = t->sites & IVR_FP8_SITE_FC2;
+    // dtype of each site's A operand (LN output / attention output / MLP hidden): e4m3 where the consuming site is
+    auto kind = [&](bool site8) { return f32 ? OUT_F32 : site8 ? OUT_FP8 : OUT_BF16; };
     const int D = d.width, rows = n * T;
     int rc;
     for (int i = 0; i < d.layers; ++i) {
         const std::string p = "l" + std::to_string(i) + ".";
         if (t->debug_out && t->debug_layer == i)
             IVR_HIP(hipMemcpyAsync(t->debug_out, t->resid, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s));
-        rc = ivr_launch_layernorm(act_kind, t->resid, 1, nullptr, wptr<float>(t, p + "ln1_g"), wptr<float>(t, p + "ln1_b"), d.ln_eps,
+        rc = ivr_launch_layernorm(kind(q8), t->resid, 1, nullptr, wptr<float>(t, p + "ln1_g"), wptr<float>(t, p + "ln1_b"), d.ln_eps,
                                   t->xn, rows, D, s);
         if (rc) return rc;
         GemmArgs g;
@@ -224,9 +232,9 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.out = t->qkv;                  // bf16 in the fp8 mode too: the attention products stay on the bf16 MFMA
         g.ldo = 3 * D;
         g.tag = "gemm_qkv";
-        rc = layer_gemm(t, EPI_STORE, g, p + "qkv_w", s);
+        rc = layer_gemm(t, q8, EPI_STORE, g, p + "qkv_w", s);
         if (rc) return rc;
-        rc = ivr_launch_attention(f32, t->qkv, t->att, n, T, D, d.heads, d.causal, s, fp8);
+        rc = ivr_launch_attention(f32, t->qkv, t->att, n, T, D, d.heads, d.causal, s, o8);
         if (rc) return rc;
         g = GemmArgs();
         g.A = t->att;
@@ -239,11 +247,16 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.resid = t->resid;
         g.ldr = D;
         g.tag = "gemm_attn_out";
-        rc = layer_gemm(t, EPI_RESID, g, p + "o_w", s);
+        rc = layer_gemm(t, o8, EPI_RESID, g, p + "o_w", s);
         if (rc) return rc;
-        rc = ivr_launch_layernorm(act_kind, t->resid, 1, nullptr, wptr<float>(t, p + "ln2_g"), wptr<float>(t, p + "ln2_b"), d.ln_eps,
+        rc = ivr_launch_layernorm(kind(f18), t->resid, 1, nullptr, wptr<float>(t, p + "ln2_g"), wptr<float>(t, p + "ln2_b"), d.ln_eps,
                                   t->xn, rows, D, s);
         if (rc) return rc;
+        if (t->mlp_cls) {                // token-0 rows of the same LayerNorm in bf16 for the side path
+            rc = ivr_launch_layernorm(OUT_BF16, t->resid, T, nullptr, wptr<float>(t, p + "ln2_g"), wptr<float>(t, p + "ln2_b"), d.ln_eps,
+                                      t->xn_cls, n, D, s);
+            if (rc) return rc;
+        }
         g = GemmArgs();
         g.A = t->xn;
         g.lda = D;
@@ -255,12 +268,19 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.out = t->hid;
         g.ldo = d.mlp;
         g.act = d.act;
-        g.out8 = fp8;
+        g.out8 = f18 && f28;             // the e4m3 GEMM writes fc2's e4m3 operand itself
         g.tag = "gemm_fc1";
-        rc = layer_gemm(t, EPI_STORE, g, p + "fc1_w", s);
+        rc = layer_gemm(t, f18, EPI_STORE, g, p + "fc1_w", s);
         if (rc) return rc;
+        const void *hid_a = t->hid;
+        if (!f18 && f28) {               // bf16 fc1 feeding an e4m3 fc2 (error-budget configurations only): converted copy behind it
+            unsigned char *h8 = reinterpret_cast<unsigned char *>(t->hid) + (size_t)t->max_batch * d.tokens * d.mlp * 2;
+            rc = ivr_launch_bf16_to_e4m3(t->hid, h8, (int64_t)rows * d.mlp, s);
+            if (rc) return rc;
+            hid_a = h8;
+        }
         g = GemmArgs();
-        g.A = t->hid;
+        g.A = hid_a;
         g.lda = d.mlp;
         g.ldw = d.mlp;
         g.M = rows;
@@ -269,9 +289,40 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.bias = wptr<float>(t, p + "fc2_b");
         g.resid = t->resid;
         g.ldr = D;
+        g.skip_mod = t->mlp_cls ? T : 0;
         g.tag = "gemm_fc2";
-        rc = layer_gemm(t, EPI_RESID, g, p + "fc2_w", s);
+        rc = layer_gemm(t, f28, EPI_RESID, g, p + "fc2_w", s);
         if (rc) return rc;
+        if (t->mlp_cls) {
+            // side path: the n token-0 rows through fc1 / fc2 in bf16 (rows of image i sit T*D apart in the residual stream)
+            g = GemmArgs();
+            g.A = t->xn_cls;
+            g.lda = D;
+            g.ldw = D;
+            g.M = n;
+            g.N = d.mlp;
+            g.K = D;
+            g.bias = wptr<float>(t, p + "fc1_b");
+            g.out = t->hid_cls;
+            g.ldo = d.mlp;
+            g.act = d.act;
+            g.tag = "gemm_fc1_cls";
+            rc = layer_gemm(t, false, EPI_STORE, g, p + "fc1_w", s);
+            if (rc) return rc;
+            g = GemmArgs();
+            g.A = t->hid_cls;
+            g.lda = d.mlp;
+            g.ldw = d.mlp;
+            g.M = n;
+            g.N = D;
+            g.K = d.mlp;
+            g.bias = wptr<float>(t, p + "fc2_b");
+            g.resid = t->resid;
+            g.ldr = T * D;
+            g.tag = "gemm_fc2_cls";
+            rc = layer_gemm(t, false, EPI_RESID, g, p + "fc2_w", s);
+            if (rc) return rc;
+        }
     }
     if (t->debug_out && t->debug_layer == d.layers)
         IVR_HIP(hipMemcpyAsync(t->debug_out, t->resid, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s));
@@ -367,16 +418,21 @@ int ivr_tower_finalize(ivr_tower *t, int max_batch) {
         for (int j = 0; j < D; ++j) qb[j] = H(p + "q_b")[j] * scale;
         memcpy(&qb[D], H(p + "k_b").data(), (size_t)D * 4);
         memcpy(&qb[2 * D], H(p + "v_b").data(), (size_t)D * 4);
-        if (d.compute == IVR_COMPUTE_FP8) {
-            if ((rc = upload_fp8(t, p + "qkv_w", qkv.data(), 3 * D, D))) return rc;
-            if ((rc = upload_fp8(t, p + "o_w", H(p + "o_w").data(), D, D))) return rc;
-            if ((rc = upload_fp8(t, p + "fc1_w", H(p + "fc1_w").data(), d.mlp, D))) return rc;
-            if ((rc = upload_fp8(t, p + "fc2_w", H(p + "fc2_w").data(), D, d.mlp))) return rc;
-        } else {
-            if ((rc = upload(t, p + "qkv_w", qkv.data(), (int64_t)qkv.size(), true))) return rc;
-            if ((rc = upload(t, p + "o_w", H(p + "o_w").data(), (int64_t)D * D, true))) return rc;
-            if ((rc = upload(t, p + "fc1_w", H(p + "fc1_w").data(), (int64_t)d.mlp * D, true))) return rc;
-            if ((rc = upload(t, p + "fc2_w", H(p + "fc2_w").data(), (int64_t)d.mlp * D, true))) return rc;
+        // every site gets the operand dtype it runs in; the MLP sites keep a bf16 copy too when token 0 takes the side path
+        const struct {
+            const char *name;
+            const float *host;
+            int64_t N, K;
+            int bit;
+            bool also_bf16;
+        } site[4] = {{"qkv_w", qkv.data(), 3 * D, D, IVR_FP8_SITE_QKV, false},
+                     {"o_w", H(p + "o_w").data(), D, D, IVR_FP8_SITE_ATTN_OUT, false},
+                     {"fc1_w", H(p + "fc1_w").data(), d.mlp, D, IVR_FP8_SITE_FC1, t->mlp_cls},
+                     {"fc2_w", H(p + "fc2_w").data(), D, d.mlp, IVR_FP8_SITE_FC2, t->mlp_cls}};
+        for (const auto &st : site) {
+            const bool s8 = t->sites & st.bit;
+            if (s8 && (rc = upload_fp8(t, p + st.name, st.host, st.N, st.K))) return rc;
+            if ((!s8 || st.also_bf16) && (rc = upload(t, p + st.name, st.host, st.N * st.K, true))) return rc;
         }
         if ((rc = upload(t, p + "qkv_b", qb.data(), 3 * D, false))) return rc;
         for (const char *n : {"ln1_g", "ln1_b", "ln2_g", "ln2_b", "o_b", "fc2_b"})
@@ -390,13 +446,14 @@ int ivr_tower_finalize(ivr_tower *t, int max_batch) {
 
     // activation workspace, one allocation
     const size_t es = d.compute == IVR_COMPUTE_F32 ? 4 : 2;                       // qkv, pooled rows
-    const size_t ea = d.compute == IVR_COMPUTE_FP8 ? 1 : es;                      // GEMM A operands: LN out, attention out, MLP hidden
+    const size_t ea = es;        // GEMM A operands (LN out, attention out, MLP hidden): sized for bf16, e4m3 sites use half of it
     const size_t rows = (size_t)max_batch * d.tokens;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_resid = al(rows * D * 4), b_xn = al(rows * D * ea), b_qkv = al(rows * 3 * D * es), b_att = al(rows * D * ea),
-                 b_hid = al(rows * d.mlp * ea), b_pool = al((size_t)max_batch * D * es),
-                 b_pf = al((size_t)max_batch * std::max(D, d.out_dim) * 4), b_eos = al((size_t)max_batch * 4);
-    t->ws_bytes = b_resid + b_xn + b_qkv + b_att + b_hid + b_pool + b_pf + b_eos;
+                 b_hid = al(rows * d.mlp * (ea + (((t->sites & IVR_FP8_SITE_FC2) && !(t->sites & IVR_FP8_SITE_FC1)) ? 1 : 0))), b_pool = al((size_t)max_batch * D * es),
+                 b_pf = al((size_t)max_batch * std::max(D, d.out_dim) * 4), b_eos = al((size_t)max_batch * 4),
+                 b_xc = t->mlp_cls ? al((size_t)max_batch * D * 2) : 0, b_hc = t->mlp_cls ? al((size_t)max_batch * d.mlp * 2) : 0;
+    t->ws_bytes = b_resid + b_xn + b_qkv + b_att + b_hid + b_pool + b_pf + b_eos + b_xc + b_hc;
     IVR_HIP(hipMalloc(&t->ws, t->ws_bytes));
     IVR_HIP(hipMemset(t->ws, 0, t->ws_bytes));
     unsigned char *p = reinterpret_cast<unsigned char *>(t->ws);
@@ -415,6 +472,10 @@ int ivr_tower_finalize(ivr_tower *t, int max_batch) {
     t->pooled_f32 = reinterpret_cast<float *>(p);
     p += b_pf;
     t->eos_pos = reinterpret_cast<int *>(p);
+    p += b_eos;
+    t->xn_cls = p;
+    p += b_xc;
+    t->hid_cls = p;
     t->max_batch = max_batch;
     t->finalized = true;
     return IVR_OK;

@@ -23,6 +23,8 @@ struct GemmArgs {
     const float *colscale = nullptr;   // fp8 GEMM: per-output-column dequantisation scale [N] (NULL = 1)
     int out8 = 0;                  // fp8 GEMM, EPI_STORE: write saturated e4m3 instead of bf16
     int wide_epi = 0;              // set by the launcher: 256 x 256 kernel may use the row-wide LDS-staged epilogue
+    int skip_mod = 0;              // EPI_RESID: rows r with r % skip_mod == 0 are left untouched (0 = none); the fp8 mode's
+                                   // token-0 rows are updated by a bf16 side GEMM instead
 };
 
 int ivr_launch_gemm(bool f32, int epi, const GemmArgs &g, hipStream_t s);
@@ -35,4 +37,5 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
 int ivr_launch_vision_cls(float *resid, const float *cls, const float *pos, int n, int T, int D, hipStream_t s);
 int ivr_launch_text_embed(float *resid, const int64_t *ids, const float *tok, const float *pos, int q, int T, int D, int vocab,
                           int eos, int *eos_pos, hipStream_t s);
+int ivr_launch_bf16_to_e4m3(const void *src, void *dst, int64_t count, hipStream_t s);   // saturating RNE, count % 8 == 0
 int ivr_launch_f_normalize(const float *x, float *out, int n, int d, int normalize, hipStream_t s);

@@ -202,6 +202,18 @@ __global__ __launch_bounds__(256) void f_normalize_kernel(const float *__restric
     for (int k = lane; k < d; k += 64) out[(int64_t)row * d + k] = p[k] / den;
 }
 
+// bf16 -> saturated e4m3, 8 elements per thread (a bf16 fc1 feeding an e4m3 fc2: error-budget configurations of the fp8 mode)
+__global__ __launch_bounds__(256) void bf16_to_e4m3_kernel(const uint4 *__restrict__ src, uint2 *__restrict__ dst, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float f[8];
+    El<unsigned short>::unpack(src[i], f);
+    uint2 o;
+    o.x = ivr_pack_fp8x4(f[0], f[1], f[2], f[3]);
+    o.y = ivr_pack_fp8x4(f[4], f[5], f[6], f[7]);
+    dst[i] = o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------
@@ -372,7 +384,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                 r.y += acc[nt][mt][1] + bv[nt].y;
                 r.z += acc[nt][mt][2] + bv[nt].z;
                 r.w += acc[nt][mt][3] + bv[nt].w;
-                if (mok[mt] && nok[nt]) *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
+                if (mok[mt] && nok[nt] && !(EPI == EPI_RESID && g.skip_mod && mrow[mt] % g.skip_mod == 0))
+                    *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
             }
     } else {
 #pragma unroll
@@ -502,7 +515,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4]
                 for (int it = 0; it < 8; ++it) {
                     const int R = (b8 * 8 + it) * 4 + (lane >> 4), grow = row0 + half * 64 + R;
                     const float4 v = *reinterpret_cast<const float4 *>(wb + R * 256 + (((lane & 15) ^ (R & 15)) << 4));
-                    if (grow < g.M)
+                    if (grow < g.M && !(g.skip_mod && grow % g.skip_mod == 0))
                         *reinterpret_cast<float4 *>(resp + (int64_t)grow * g.ldr) =
                             make_float4(rv[it].x + v.x, rv[it].y + v.y, rv[it].z + v.z, rv[it].w + v.w);
                 }
@@ -758,7 +771,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
                     r.y += a[1] + bv[nt].y;
                     r.z += a[2] + bv[nt].z;
                     r.w += a[3] + bv[nt].w;
-                    if (mok[mt] && nok[nt]) *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
+                    if (mok[mt] && nok[nt] && !(EPI == EPI_RESID && g.skip_mod && mrow[mt] % g.skip_mod == 0))
+                        *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
                 }
         } else {
 #pragma unroll
@@ -1568,12 +1582,7 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     const int group_env = std::max(0, env_int("IVR_GEMM_GROUP_M", 0)), wide_env = env_int("IVR_GEMM_WIDE_EPI", 1);
     GemmArgs ga = g;
     if (mode == 4) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS));
-            attr_done = true;
-        }
+        if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT>), DEEP_LDS)) return rc;
         const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
         ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 4);     // measured (sweep 2..16): within 2 %, narrow outputs want short groups
         // the row-wide epilogue needs whole 64-column wave blocks (N % 64 == 0) and 16-byte aligned rows
@@ -1588,12 +1597,7 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
         return IVR_OK;
     }
     const int MT = (g.M + BM - 1) / BM, NT = (g.N + BN - 1) / BN;
-    static bool attr_done = false;
-    if (!attr_done) {
-        IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<T, EPI, ACT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-        attr_done = true;
-    }
+    if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(gemm_kernel<T, EPI, ACT>), GEMM_LDS)) return rc;
     ga.group_m = group_env ? group_env : 8;
     const int grid = 8 * ((MT + 7) / 8) * NT;               // every XCD gets the same number of ids; surplus ones exit
     hipLaunchKernelGGL((gemm_kernel<T, EPI, ACT>), dim3(grid), dim3(256), GEMM_LDS, s, ga);
@@ -1632,12 +1636,7 @@ namespace {
 template <int EPI, int ACT, bool OUT8>
 int launch_gemm8_t(const GemmArgs &g, hipStream_t s) {
     IvrProf prof(g.tag ? g.tag : "gemm_fp8", s, 2.0 * g.M * g.N * g.K);
-    static bool attr_done = false;
-    if (!attr_done) {
-        IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big8_kernel<EPI, ACT, OUT8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS));
-        attr_done = true;
-    }
+    if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(gemm_big8_kernel<EPI, ACT, OUT8>), DEEP_LDS)) return rc;
     const int group_env = std::max(0, env_int("IVR_GEMM_GROUP_M", 0));
     GemmArgs ga = g;
     const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
@@ -1718,14 +1717,9 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
                 const int nsplit = ivr_ceil_div(ntiles, 6 * QC);
                 const int tps = ivr_ceil_div(ntiles, nsplit), nw = ivr_ceil_div(tps, QC);
                 const int lds = 2 * Tp * 128;
-                static int attr_lds = 0;
-                if (lds > attr_lds) {
-                    IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_head_kernel<QC, unsigned short, MINW>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                    IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_head_kernel<QC, unsigned char, MINW>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                    attr_lds = lds;
-                }
+                if (int rc = out_fp8 ? ivr_func_max_lds(reinterpret_cast<const void *>(attention_head_kernel<QC, unsigned char, MINW>), lds)
+                                     : ivr_func_max_lds(reinterpret_cast<const void *>(attention_head_kernel<QC, unsigned short, MINW>), lds))
+                    return rc;
                 const dim3 grid((unsigned)((int64_t)n * heads * nsplit)), block(64 * nw);
                 if (out_fp8)
                     hipLaunchKernelGGL((attention_head_kernel<QC, unsigned char, MINW>), grid, block, lds, s, (const unsigned short *)qkv,
@@ -1758,24 +1752,27 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(s, &cap);
             if (cap != hipStreamCaptureStatusNone || n * heads < 512) return run(3);       // too small to time meaningfully
-            hipEvent_t e[4];
-            for (auto &ev : e) IVR_HIP(hipEventCreate(&ev));
+            hipEvent_t e[2] = {nullptr, nullptr};
             int rc = IVR_OK, best = 3;
             float best_ms = 0.f;
+            // no early return between here and the hipEventDestroy below: every failure is carried in rc
+            if (hipEventCreate(&e[0]) != hipSuccess || hipEventCreate(&e[1]) != hipSuccess)
+                rc = ivr_fail(IVR_ERR_HIP, "attention autotune: hipEventCreate failed");
             for (int qc = 3; qc <= 5 && rc == IVR_OK; ++qc) {
                 rc = run(qc);                                 // warm-up (function attributes, caches)
-                IVR_HIP(hipEventRecord(e[0], s));
+                if (rc == IVR_OK && hipEventRecord(e[0], s) != hipSuccess) rc = ivr_fail(IVR_ERR_HIP, "attention autotune: hipEventRecord");
                 if (rc == IVR_OK) rc = run(qc);
-                IVR_HIP(hipEventRecord(e[1], s));
-                IVR_HIP(hipEventSynchronize(e[1]));
                 float ms = 0.f;
-                IVR_HIP(hipEventElapsedTime(&ms, e[0], e[1]));
-                if (qc == 3 || ms < best_ms) {
+                if (rc == IVR_OK && (hipEventRecord(e[1], s) != hipSuccess || hipEventSynchronize(e[1]) != hipSuccess ||
+                                     hipEventElapsedTime(&ms, e[0], e[1]) != hipSuccess))
+                    rc = ivr_fail(IVR_ERR_HIP, "attention autotune: event timing failed");
+                if (rc == IVR_OK && (qc == 3 || ms < best_ms)) {
                     best = qc;
                     best_ms = ms;
                 }
             }
-            for (auto &ev : e) (void)hipEventDestroy(ev);
+            for (auto &ev : e)
+                if (ev) (void)hipEventDestroy(ev);
             if (rc != IVR_OK) return rc;
             {
                 std::lock_guard<std::mutex> lk(tune_mu);
@@ -1796,8 +1793,7 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
     IVR_REQUIRE(threads <= 512, "attention: T=%d too long for the float32 kernel", T);
     const size_t lds = (size_t)2 * T * 64 * 4;
     IVR_REQUIRE(lds <= 160 * 1024, "attention: T=%d needs %zu bytes of LDS", T, lds);
-    IVR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
+    if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(attention_kernel<float>), (int)lds)) return rc;
     hipLaunchKernelGGL(attention_kernel<float>, dim3(heads, n), dim3(threads), lds, s, (const float *)qkv, (float *)att, T, D, causal);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
@@ -1816,6 +1812,16 @@ int ivr_launch_text_embed(float *resid, const int64_t *ids, const float *tok, co
     hipLaunchKernelGGL(text_embed_kernel, dim3(q * T), dim3(256), 0, s, resid, ids, tok, pos, T, D, vocab);
     IVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(eos_pos_kernel, dim3((unsigned)ivr_ceil_div(q, 256)), dim3(256), 0, s, ids, q, T, eos, eos_pos);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+int ivr_launch_bf16_to_e4m3(const void *src, void *dst, int64_t count, hipStream_t s) {
+    if (count <= 0) return IVR_OK;
+    IVR_REQUIRE(count % 8 == 0, "bf16_to_e4m3: count=%lld must be a multiple of 8", (long long)count);
+    IvrProf prof("bf16_to_e4m3", s, (double)count * 3);
+    hipLaunchKernelGGL(bf16_to_e4m3_kernel, dim3((unsigned)ivr_ceil_div(count / 8, 256)), dim3(256), 0, s, (const uint4 *)src, (uint2 *)dst,
+                       count / 8);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }

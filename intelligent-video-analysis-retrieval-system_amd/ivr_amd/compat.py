@@ -135,15 +135,40 @@ class ByteTokenizer:
         return ids
 
 
+def _load_local_checkpoint(path):
+    """A local HuggingFace checkpoint directory (the reference's `paths.models`/clip_model override, system.py:1435):
+    state dict from model.safetensors, or pytorch_model.bin through torch.load(weights_only=True) - loaders that execute
+    nothing from the file.  Returns (state_dict of numpy arrays, parsed config.json or {})."""
+    cfg = {}
+    cj = os.path.join(path, "config.json")
+    if os.path.isfile(cj):
+        with open(cj, encoding="utf-8") as f:
+            cfg = json.load(f)
+    st = os.path.join(path, "model.safetensors")
+    if os.path.isfile(st):
+        from safetensors.numpy import load_file
+        return load_file(st), cfg
+    pb = os.path.join(path, "pytorch_model.bin")
+    if os.path.isfile(pb):
+        sd = torch.load(pb, map_location="cpu", weights_only=True)
+        return {k: v.float().numpy() for k, v in sd.items()}, cfg
+    raise FileNotFoundError(f"{path}: neither model.safetensors nor pytorch_model.bin")
+
+
 class CLIPFeatureExtractor:
-    """core.py:1384.  `weights`/`text_weights`: canonical float32 dicts (ivr_amd.weights), a HF state dict, or None
-    for seeded random-init weights of the named architecture (no network for checkpoints)."""
+    """core.py:1384.  Where the weights come from, in this order:
+      * `weights` / `text_weights`: canonical float32 dicts (ivr_amd.weights) or a HF state dict;
+      * `model_path` naming a local checkpoint directory (model.safetensors / pytorch_model.bin + config.json, the layout
+        CLIPModel.from_pretrained reads at core.py:1442) - there is no network, hub names are never fetched;
+      * `allow_random_init=True`: seeded random-init weights of the architecture `model_path` names.  For tests and
+        benchmarks only: the embeddings are meaningless for retrieval, so this is never taken silently."""
 
     ARCH = {"openai/clip-vit-base-patch32": (C.CLIP_VIT_B32, C.CLIP_TEXT_B32),
             "openai/clip-vit-large-patch14": (C.CLIP_VIT_L14, C.CLIP_TEXT_L14)}
 
     def __init__(self, model_path="openai/clip-vit-large-patch14", config=None, logger=None, weights=None,
-                 text_weights=None, tokenizer=None, max_batch=256, compute="bf16", seed=0, with_text=True):
+                 text_weights=None, tokenizer=None, max_batch=256, compute="bf16", seed=0, with_text=True,
+                 allow_random_init=False, decode_workers=None):
         self.config = config
         self.logger = logger or _NullLogger()
         self.model_path = model_path
@@ -152,17 +177,56 @@ class CLIPFeatureExtractor:
         self.device = "cuda"
         self.max_batch_size = 32          # core.py:1420 (the reference's processing granularity)
         self.max_text_length = 77
-        vis_cfg, txt_cfg = self.ARCH.get(model_path, self.ARCH["openai/clip-vit-large-patch14"])
+        local_sd = None
+        if model_path in self.ARCH:
+            vis_cfg, txt_cfg = self.ARCH[model_path]
+        elif isinstance(model_path, str) and os.path.isdir(model_path):
+            local_sd, hf_cfg = _load_local_checkpoint(model_path)
+            width = int(hf_cfg.get("vision_config", {}).get("hidden_size", 0)) or int(
+                np.asarray(local_sd["vision_model.embeddings.class_embedding"]).shape[0])
+            by_width = {c[0].width: c for c in self.ARCH.values()}
+            if width not in by_width:
+                raise ValueError(f"{model_path}: vision width {width} is not one of the supported CLIP towers {sorted(by_width)}")
+            vis_cfg, txt_cfg = by_width[width]
+        else:
+            raise ValueError(f"unknown model_path {model_path!r}: expected one of {sorted(self.ARCH)} or a local checkpoint directory")
         self.vision_config, self.text_config = vis_cfg, txt_cfg
         self._lock = threading.RLock()    # encode_images is called from 4 worker threads (unified_index.py:773)
+        self.decode_workers = decode_workers
+        if weights is None and local_sd is not None:
+            weights = local_sd
+        if text_weights is None and local_sd is not None and with_text:
+            text_weights = local_sd
+        self.random_init = weights is None or (with_text and text_weights is None)
+        if self.random_init:
+            if not allow_random_init:
+                raise RuntimeError(
+                    f"CLIPFeatureExtractor({model_path!r}): no weights - pass weights= (HF state dict or canonical dict), a local "
+                    "checkpoint directory as model_path, or allow_random_init=True (tests / benchmarks: embeddings of "
+                    "random-init towers are meaningless for retrieval); hub names are not fetched, there is no network")
+            self.logger.warning("CLIPFeatureExtractor: RANDOM-INIT weights (allow_random_init=True): not a trained model",
+                                model_path=model_path, seed=seed)
         w = self._resolve(vis_cfg, weights, seed)
         self.vision_model = Tower(vis_cfg, w, max_batch=max_batch, compute=compute)
         self.text_model = None
         if with_text:
             tw = self._resolve(txt_cfg, text_weights, seed + 1)
-            self.text_model = Tower(txt_cfg, tw, max_batch=64, compute=compute)
+            self.text_model = Tower(txt_cfg, tw, max_batch=64, compute="bf16" if compute.startswith("fp8") else compute)
         self.model = self.vision_model    # truthy: health check at system.py:263
-        self.processor = tokenizer or ByteTokenizer(txt_cfg)
+        if tokenizer is None and isinstance(model_path, str) and os.path.isfile(os.path.join(model_path, "vocab.json")):
+            try:                          # the checkpoint's own BPE tokenizer, local files only
+                from transformers import CLIPTokenizerFast
+                tk = CLIPTokenizerFast.from_pretrained(model_path, local_files_only=True)
+                tokenizer = lambda texts, max_length=77: tk(list(texts), padding="max_length", truncation=True,   # noqa: E731
+                                                            max_length=max_length, return_tensors="np")["input_ids"]
+            except Exception as e:        # pragma: no cover - depends on the checkpoint directory
+                self.logger.warning("CLIP tokenizer files found but not loadable", error=str(e))
+        if tokenizer is None:
+            if not self.random_init:
+                self.logger.warning("CLIPFeatureExtractor: no CLIP BPE tokenizer given (tokenizer=): encode_text falls back to a "
+                                    "byte-level stand-in whose ids do NOT match a trained text tower")
+            tokenizer = ByteTokenizer(txt_cfg)
+        self.processor = tokenizer
         self.nlp = None
 
     @staticmethod
@@ -641,10 +705,18 @@ class FrameFilter:
     video_frame_filter.extract_unique_frames)."""
 
     def __init__(self, weights=None, mean=C.IMAGENET_MEAN, std=C.IMAGENET_STD, max_batch=256, compute="bf16", seed=0,
-                 threshold=SIM_THRESHOLD):
+                 threshold=SIM_THRESHOLD, allow_random_init=False, logger=None):
         cfg = C.DINO_VIT_S16
+        if isinstance(weights, str):                         # local facebook/dino-vits16 checkpoint directory
+            weights, _ = _load_local_checkpoint(weights)
+        if weights is None:
+            if not allow_random_init:
+                raise RuntimeError("FrameFilter: no weights - pass weights= (HF ViTModel state dict, canonical dict or a local "
+                                   "checkpoint directory) or allow_random_init=True (tests / benchmarks only); "
+                                   "video_frame_filter.py:24-25 fetches facebook/dino-vits16 by name, there is no network here")
+            (logger or _NullLogger()).warning("FrameFilter: RANDOM-INIT DINO weights (allow_random_init=True)", seed=seed)
         w = make_weights(cfg, seed) if weights is None else (
-            from_hf_state_dict(cfg, weights) if any(k.startswith("embeddings.") for k in weights) else weights)
+            from_hf_state_dict(cfg, weights) if any(k.startswith(("embeddings.", "encoder.", "layers.")) for k in weights) else weights)
         self.tower = Tower(cfg, w, max_batch=max_batch, compute=compute)
         self.mean, self.std, self.threshold = mean, std, threshold
         self.state = DedupState(cfg.width)
@@ -676,10 +748,16 @@ class FrameFilter:
 _default_filter = None
 
 
-def _filter():
+def set_default_frame_filter(frame_filter):
+    """Install the FrameFilter behind the module-level extract_embedding / extract_unique_frames (the reference builds its
+    model at import time from the hub, video_frame_filter.py:24-25; here the weights must be handed over explicitly)."""
     global _default_filter
+    _default_filter = frame_filter
+
+
+def _filter():
     if _default_filter is None:
-        _default_filter = FrameFilter()
+        raise RuntimeError("no default FrameFilter: call set_default_frame_filter(FrameFilter(weights=...)) first")
     return _default_filter
 
 

@@ -36,9 +36,10 @@ class StreamingSession:
         self.index.reserve_search(self.queries.shape[0], self.k)
         self.graph = None
         if use_graph:
-            # warm-up on a side stream (lazy allocations, function attributes, lookup tables), then capture
+            # warm-up on the session's own stream (lazy allocations, function attributes, lookup tables, and the per-stream
+            # preprocess scratch, which cannot be allocated during capture), then capture on that SAME stream
             cur0 = self.cursor.clone()
-            s = torch.cuda.Stream(device=dev)
+            s = self.stream = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
                 self._enqueue()
@@ -46,7 +47,7 @@ class StreamingSession:
             torch.cuda.synchronize(dev)
             self.cursor.copy_(cur0)          # the warm-up wrote zero frames into slot 0; the first real step overwrites it
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=s):
                 self._enqueue()
             self.cursor.copy_(cur0)
 

@@ -4,8 +4,12 @@ Stands in for the HuggingFace modules the reference calls at `core.py:1619`
 (`CLIPModel.get_image_features`), `core.py:1541` (`get_text_features`) and
 `video_frame_filter.py:31` (`ViTModel`).  Weights are the float32 master dict of
 `ivr_amd.weights` (synthetic or converted from an HF state dict); GEMM operands are
-cast to bf16 at upload unless `compute="f32"` (verification mode); `compute="fp8"` (BASELINE config 5) quantises the
-four linear layers of every block to e4m3 with one scale per output channel.
+cast to bf16 at upload unless `compute="f32"` (verification mode).  The e4m3 modes (BASELINE config 5) quantise
+linear sites of every block to e4m3 with one scale per output channel:
+  compute="fp8"      the MLP sites (fc1, fc2 = two thirds of the FLOPs) in e4m3, the token-0 rows of those sites on a bf16
+                     side path: the assignment that keeps 1 - cos(embedding, f32 embedding) <= 1e-3
+  compute="fp8_all"  all four sites (qkv, attn-out, fc1, fc2) in e4m3: fastest, 1 - cos ~ 4e-3 (3 mantissa bits)
+  fp8_sites=(...), fp8_cls_bf16=...  explicit assignment (tools/fp8_error_budget*.py)
 """
 import ctypes as C
 
@@ -18,10 +22,23 @@ from .preprocess import preprocess_frames
 
 
 class Tower:
-    def __init__(self, cfg: TowerConfig, weights, max_batch=256, compute="bf16", device=None):
+    def __init__(self, cfg: TowerConfig, weights, max_batch=256, compute="bf16", device=None, fp8_sites=None, fp8_cls_bf16=None):
         self._lib = _ffi.load()
         self.cfg = cfg
         self.compute = compute
+        sites, cls = 0, 0
+        if compute in ("fp8", "fp8_all"):
+            if fp8_sites is None:
+                fp8_sites = ("fc1", "fc2") if compute == "fp8" else ("qkv", "o", "fc1", "fc2")
+            if fp8_cls_bf16 is None:
+                fp8_cls_bf16 = compute == "fp8"
+            sites = sum(_ffi.FP8_SITE[s] for s in set(fp8_sites))
+            if sites == 0:
+                raise ValueError("fp8_sites is empty: use compute='bf16'")
+            cls = int(bool(fp8_cls_bf16))
+        elif fp8_sites is not None or fp8_cls_bf16 is not None:
+            raise ValueError("fp8_sites / fp8_cls_bf16 only apply to compute='fp8' / 'fp8_all'")
+        self.fp8_sites, self.fp8_cls_bf16 = sites, cls
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
         self.max_batch = int(max_batch)
         # patch-major pixels stay bf16 in the fp8 mode (only the four GEMMs of every block run on the fp8 MFMA)
@@ -30,7 +47,8 @@ class Tower:
                            mlp=cfg.mlp, tokens=cfg.tokens, out_dim=cfg.out_dim, act=cfg.act, pool=cfg.pool,
                            image=cfg.image, patch=cfg.patch, pre_ln=int(cfg.pre_ln), patch_bias=int(cfg.patch_bias),
                            vocab=cfg.vocab, eos_id=cfg.eos_id, causal=int(cfg.causal),
-                           compute={"bf16": 0, "f32": 1, "fp8": 2}[compute], ln_eps=cfg.ln_eps)
+                           compute={"bf16": 0, "f32": 1, "fp8": 2, "fp8_all": 2}[compute], ln_eps=cfg.ln_eps,
+                           fp8_sites=sites, fp8_mlp_cls_bf16=cls)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _ffi.check(self._lib.ivr_tower_create(_ffi.context(self.device.index), C.byref(d), C.byref(h)),

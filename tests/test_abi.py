@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_ffi.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in ivr_api.h but not exported"
-    assert _ffi.load().ivr_api_version() == 1
+    assert _ffi.load().ivr_api_version() == _ffi.API_VERSION
 
 
 def test_error_slot_without_gpu():

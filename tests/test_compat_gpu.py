@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def extractor():
     from ivr_amd.compat import CLIPFeatureExtractor
-    return CLIPFeatureExtractor("openai/clip-vit-base-patch32", max_batch=32, seed=3)
+    return CLIPFeatureExtractor("openai/clip-vit-base-patch32", max_batch=32, seed=3, allow_random_init=True)
 
 
 @pytest.fixture(scope="module")
@@ -122,7 +122,9 @@ def test_unified_index_build_load_search(extractor, keyframes, tmp_path):
     assert np.all(np.diff([h["similarity_score"] for h in hits]) >= 0)          # 1 - ip rises with rank
     assert hits[0]["metadata"]["image_name"] == os.path.basename(sorted(paths)[6])
     only_v1 = ui.search_vectors(q, k=10, filter_func=lambda m: m["folder_name"] == "L01_V001")
-    assert {h["metadata"]["folder_name"] for h in only_v1} == {"L01_V001"} and only_v1[0]["rank"] > 0 or True
+    assert only_v1 and {h["metadata"]["folder_name"] for h in only_v1} == {"L01_V001"}
+    # ranks stay the positions in the unfiltered FAISS order (unified_index.py:507-526): a subsequence of 0..9
+    assert [h["rank"] for h in only_v1] == [h["rank"] for h in hits if h["metadata"]["folder_name"] == "L01_V001"]
     with UnifiedIndex() as again:
         info = again.load_unified_index(str(tmp_path / "idx"))
         assert info["vectors_count"] == 10
@@ -147,7 +149,7 @@ def test_unified_index_build_load_search(extractor, keyframes, tmp_path):
 def test_frame_filter_dedup_pipeline():
     """video_frame_filter.py:53-85 on decoded BGR frames: stretch-resize, DINO CLS embedding, keep iff cos < 0.98."""
     from ivr_amd.compat import FrameFilter
-    ff = FrameFilter(max_batch=16, seed=14, compute="f32")
+    ff = FrameFilter(max_batch=16, seed=14, compute="f32", allow_random_init=True)
     base = smooth_frames(7, 6, 180, 320)
     frames = np.stack([base[0], base[0], base[1], base[1], base[1], base[2], base[3], base[3], base[4], base[5]] * 2)[..., ::-1]
     frames = np.ascontiguousarray(frames)
@@ -192,3 +194,47 @@ def test_legacy_save_load_and_threaded_encode(extractor, keyframes, tmp_path):
     with ThreadPoolExecutor(max_workers=4) as ex:
         single = list(ex.map(lambda p: extractor.encode_images([p], show_progress=False)[0], sorted(paths)))
     assert ((np.stack(single) * feats).sum(1) > 1 - 1e-6).all()         # same rows as the batched call
+
+
+def test_weights_are_never_random_by_accident(tmp_path):
+    """the reference's own call shape CLIPFeatureExtractor(model_path, config, logger) must not hand back
+    random-init towers silently; unknown names are rejected; a local HF checkpoint directory is loaded."""
+    from safetensors.numpy import save_file
+    from ivr_amd.compat import CLIPFeatureExtractor, FrameFilter, extract_embedding, set_default_frame_filter
+    from ivr_amd.weights import to_hf_state_dict
+    import json
+    with pytest.raises(RuntimeError, match="allow_random_init"):
+        CLIPFeatureExtractor("openai/clip-vit-base-patch32")
+    with pytest.raises(ValueError, match="unknown model_path"):
+        CLIPFeatureExtractor("openai/clip-vit-huge-patch99", allow_random_init=True)
+    with pytest.raises(RuntimeError, match="allow_random_init"):
+        FrameFilter()
+    set_default_frame_filter(None)
+    with pytest.raises(RuntimeError, match="set_default_frame_filter"):
+        extract_embedding(None)
+
+    class Log:
+        def __init__(self):
+            self.lines = []
+
+        def warning(self, msg, **kw):
+            self.lines.append(msg)
+
+        def __getattr__(self, _):
+            return lambda *a, **k: None
+    log = Log()
+    CLIPFeatureExtractor("openai/clip-vit-base-patch32", logger=log, allow_random_init=True, with_text=False, max_batch=4)
+    assert any("RANDOM-INIT" in ln for ln in log.lines)
+    # a local checkpoint directory in the HF layout (vision tower only, to keep the file small enough for a test)
+    cfg = C.CLIP_VIT_B32
+    w = make_weights(cfg, 31)
+    ckpt = tmp_path / "clip_model"
+    ckpt.mkdir()
+    save_file({k: np.ascontiguousarray(v) for k, v in to_hf_state_dict(cfg, w).items()}, str(ckpt / "model.safetensors"))
+    (ckpt / "config.json").write_text(json.dumps({"vision_config": {"hidden_size": 768}}))
+    ex = CLIPFeatureExtractor(str(ckpt), with_text=False, max_batch=4)
+    assert not ex.random_init and ex.vision_config is cfg
+    frames = synth_frames(8, 3, 224, 224)
+    got = ex.encode_frames(frames).cpu().numpy()
+    ref = V.vision_forward(cfg, w, P.preprocess(frames, "identity", C.CLIP_MEAN, C.CLIP_STD))
+    assert ((got * ref).sum(1) > 1 - 1e-4).all()

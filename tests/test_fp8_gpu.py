@@ -4,9 +4,13 @@ Two layers of checks, tolerances written here:
   * the fp8 GEMM kernel against a float32 product of the SAME e4m3 operands (torch's float8_e4m3fn -> float32 is exact),
     so only accumulation order and the output rounding differ: bf16 output 2^-8 relative, e4m3 output one e4m3 step
     (2^-3 relative, compared after dequantisation), float32 residual 1e-4 relative to the row scale;
-  * the whole tower in fp8 mode against the float32 HF golden vectors.  e4m3 carries 3 mantissa bits, so this mode does
-    NOT meet the 1e-3 score bound of the bf16 mode: the bound asserted is cosine >= 0.99 and the measured value is
-    printed.  north_star states no tolerance for configs[4]; this one is ours.
+  * the whole tower against the float32 HF golden vectors, per assignment of the four linear sites to e4m3
+    (oracle/quant_ref.py + tools/fp8_error_budget.py give the CPU-emulated budget, profiles/r02_fp8_error_budget.json):
+      compute="fp8"      fc1 + fc2 in e4m3, token-0 rows of those sites in bf16: 1 - cos <= 1e-3 asserted (emulated 4-5e-4)
+      compute="fp8_all"  all four sites: e4m3 carries 3 mantissa bits, 1 - cos ~ 3-4e-3; asserted cosine >= 0.99
+    and against the operand-rounding EMULATION of the same assignment, which pins where the kernels quantise;
+  * configs[4] as one workload: ViT-L/14 e4m3 rows in a 768-d index, mixed text + image queries, ids exact against the
+    oracle search over the same rows, |score - f32-oracle score| reported against the 1e-3 north-star bound.
 """
 import numpy as np
 import pytest
@@ -92,18 +96,122 @@ def test_fp8_gemm_rejects_bad_shapes():
         linear_fp8(x8, w8)                                        # N % 64 != 0
 
 
-@pytest.mark.parametrize("cfg,n", [(C.TINY_VIT, 4), (C.CLIP_VIT_B32, 8), (C.DINO_VIT_S16, 2), (C.CLIP_VIT_L14, 2)],
-                         ids=lambda v: getattr(v, "name", str(v)))
-def test_vision_tower_fp8_mode(cfg, n, golden):
+CASES = [(C.TINY_VIT, 4), (C.CLIP_VIT_B32, 8), (C.DINO_VIT_S16, 2), (C.CLIP_VIT_L14, 2)]
+
+
+@pytest.mark.parametrize("cfg,n", CASES, ids=lambda v: getattr(v, "name", str(v)))
+def test_vision_tower_fp8_all_sites(cfg, n, golden):
     from test_tower_gpu import _cos, _vision
     g = golden("towers")
-    _, _, _, out = _vision(cfg, "fp8", n)
+    _, _, _, out = _vision(cfg, "fp8_all", n)
     ref = g[cfg.name + "_emb"][:n]
     cos = _cos(out, ref)
-    _, _, _, out_bf16 = _vision(cfg, "bf16", n)
-    print(f"{cfg.name} fp8 min cos to fp32 HF={cos.min():.5f} (bf16 mode: {_cos(out_bf16, ref).min():.6f})")
+    print(f"{cfg.name} fp8_all (qkv, attn-out, fc1, fc2 in e4m3) 1 - min cos to fp32 HF = {1 - cos.min():.2e}")
     assert cos.min() > 0.99
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("cfg,n", CASES, ids=lambda v: getattr(v, "name", str(v)))
+def test_vision_tower_fp8_default_assignment_within_1e3(cfg, n, golden):
+    """The shipped compute="fp8": MLP sites in e4m3, token-0 rows of those sites in bf16 -> inside the 1e-3 bound."""
+    from test_tower_gpu import _cos, _vision
+    g = golden("towers")
+    tw, _, _, out = _vision(cfg, "fp8", n)
+    assert tw.fp8_sites == 12 and tw.fp8_cls_bf16 == 1
+    ref = g[cfg.name + "_emb"][:n]
+    cos = _cos(out, ref)
+    print(f"{cfg.name} fp8 (fc1+fc2 e4m3, token-0 rows bf16) 1 - min cos to fp32 HF = {1 - cos.min():.2e}")
+    assert 1 - cos.min() <= 1e-3
+    assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-5
+
+
+SITE_SETS = [("qkv",), ("o",), ("fc1",), ("fc2",), ("fc1", "fc2"), ("qkv", "o", "fc1", "fc2")]
+
+
+@pytest.mark.parametrize("sites", SITE_SETS, ids=lambda s: "+".join(s))
+@pytest.mark.parametrize("cls_bf16", [False, True])
+def test_fp8_site_assignments_match_emulation(sites, cls_bf16):
+    """Every single-site assignment (and the two shipped ones) on ViT-B/32: the HIP tower must sit much closer to the CPU
+    operand-rounding emulation of the SAME assignment than to the float32 oracle (the e4m3 error is deterministic: the same
+    operands are rounded at the same points), and its distance to the float32 oracle must match the emulated budget."""
+    from ivr_amd.tower import Tower
+    from ivr_amd.weights import make_weights
+    from conftest import synth_frames
+    from oracle import preprocess_ref as P
+    from oracle import quant_ref as QR
+    from oracle import vit_ref as V
+    if cls_bf16 and not ({"fc1", "fc2"} & set(sites)):
+        pytest.skip("the bf16 side path only exists for the MLP sites")
+    cfg = C.CLIP_VIT_B32
+    w = make_weights(cfg, 12)
+    frames = synth_frames(99, 6, 224, 224)
+    px = P.preprocess(frames, "identity", C.CLIP_MEAN, C.CLIP_STD)
+    ref = V.vision_forward(cfg, w, px)
+    # the emulation's side path covers every e4m3 site; the kernels' only the MLP sites - emulate exactly what runs
+    spec = QR.QuantSpec(sites, keep_rows=(0,) if cls_bf16 else None)
+    spec.keep_sites = {"fc1", "fc2"}
+    emu = QR.vision_forward(cfg, w, px, spec)
+    out = Tower(cfg, w, max_batch=6, compute="fp8_all", fp8_sites=sites, fp8_cls_bf16=cls_bf16).encode_frames(frames).cpu().numpy()
+    d_ref, d_emu, e_ref = 1 - (out * ref).sum(1).min(), 1 - (out * emu).sum(1).min(), 1 - (emu * ref).sum(1).min()
+    print(f"sites={'+'.join(sites)} cls_bf16={cls_bf16}: 1-cos gpu/f32 {d_ref:.2e}, emulation/f32 {e_ref:.2e}, gpu/emulation {d_emu:.2e}")
+    # Rounding to 3 mantissa bits amplifies last-bit differences (accumulation order, fast exp): an element whose pre-rounding
+    # value moves across an e4m3 boundary changes by a whole step, so two exact-arithmetic-equivalent runs decorrelate layer by
+    # layer and only agree to a fraction of the quantisation noise (measured 0.03 - 0.5 of it, least where attention averages
+    # the perturbation).  What must hold: the HIP tower is closer to the emulation than the emulation is to float32, and its
+    # distance to float32 IS the emulated budget (measured within 8 %).
+    assert d_emu <= 0.75 * e_ref + 2e-5
+    assert 0.7 * e_ref - 2e-5 <= d_ref <= 1.4 * e_ref + 2e-5
+
+
+def test_config4_workload_fp8_rows_mixed_queries():
+    """BASELINE configs[4] at test scale as ONE workload: ViT-L/14 rows from the e4m3 tower in a 768-d index, a mixed batch of
+    image queries (same e4m3 tower) and text queries (bf16 text tower), exact top-k through the HIP search.
+      ids: bit-exact against the oracle search over the SAME rows and queries;
+      scores: against the float32 oracle towers' scores for the same frames / token ids.  The north-star bound is 1e-3; with
+      e4m3 operands (3 mantissa bits) on two thirds of the FLOPs the measured value is asserted against 3e-3 and printed -
+      profiles/r02_fp8_error_budget.json shows no e4m3 assignment reaches 1e-3 on text-vs-image scores (bf16 itself: 6e-4)."""
+    from ivr_amd.index import FlatIPIndex
+    from ivr_amd.tower import Tower
+    from ivr_amd.weights import make_weights
+    from conftest import synth_frames
+    from oracle import preprocess_ref as P
+    from oracle import search_ref as S
+    from oracle import vit_ref as V
+    vis, txt = C.CLIP_VIT_L14, C.CLIP_TEXT_L14
+    wv, wt = make_weights(vis, 12), make_weights(txt, 13)
+    n_rows, n_iq, n_tq, k = 10, 2, 6, 5
+    frames = synth_frames(1234, n_rows + n_iq, 224, 224)
+    rng = np.random.default_rng(77)
+    ids = rng.integers(1, txt.vocab - 2, (n_tq, 16)).astype(np.int64)
+    for r in range(n_tq):
+        ids[r, rng.integers(4, 16):] = txt.eos_id
+    results = {}
+    for compute in ("fp8", "fp8_all", "bf16"):
+        emb = Tower(vis, wv, max_batch=n_rows + n_iq, compute=compute).encode_frames(frames)
+        tq = Tower(txt, wt, max_batch=n_tq).encode_ids(ids)
+        idx = FlatIPIndex(768)
+        idx.add(emb[:n_rows])
+        queries = torch.cat([emb[n_rows:], tq])
+        D, I = idx.search_device(queries, k)
+        rows_h, q_h = emb[:n_rows].cpu().numpy(), queries.cpu().numpy()
+        Dr, Ir = S.flat_ip_search(rows_h, q_h, k, dtype=np.float64)
+        assert np.array_equal(I.cpu().numpy(), Ir), compute               # ids exact over the same rows
+        assert np.abs(D.cpu().numpy() - Dr).max() < 1e-5
+        results[compute] = (rows_h, q_h)
+    px = P.preprocess(frames, "identity", C.CLIP_MEAN, C.CLIP_STD)
+    ref = V.vision_forward(vis, wv, px)
+    tref = V.text_forward(txt, wt, ids)
+    Sref = np.concatenate([ref[n_rows:], tref]) @ ref[:n_rows].T
+    worst = {}
+    for compute, (rows_h, q_h) in results.items():
+        d = np.abs(q_h @ rows_h.T - Sref)
+        worst[compute] = (d[:n_iq].max(), d[n_iq:].max(), 1 - (rows_h * ref[:n_rows]).sum(1).min())
+        print(f"configs[4] {compute:8s}: max |score - f32 oracle score| image queries {d[:n_iq].max():.2e}, text queries {d[n_iq:].max():.2e}; "
+              f"1 - min cos of the rows {worst[compute][2]:.2e}")
+    assert worst["bf16"][1] <= 1e-3 and worst["bf16"][0] <= 1e-3
+    assert worst["fp8"][2] <= 1e-3 and worst["fp8"][0] <= 1e-3           # embedding bound and image-query scores inside 1e-3
+    assert worst["fp8"][1] <= 3e-3                                        # text-vs-image scores: e4m3 floor, see docstring
+    assert worst["fp8_all"][1] <= 1e-2
 
 
 def test_text_tower_fp8_mode(golden):
@@ -116,7 +224,8 @@ def test_text_tower_fp8_mode(golden):
     ids = rng.integers(0, cfg.vocab - 1, (6, cfg.tokens))
     ids[:, -3] = cfg.eos_id
     ref = np.asarray(V.text_forward(cfg, w, ids))
-    out = Tower(cfg, w, max_batch=8, compute="fp8").encode_ids(ids).cpu().numpy()
-    cos = (out * ref).sum(1) / (np.linalg.norm(out, axis=1) * np.linalg.norm(ref, axis=1))
-    print(f"tiny-text fp8 min cos={cos.min():.5f}")
-    assert cos.min() > 0.99
+    for compute in ("fp8", "fp8_all"):        # text towers pool at the EOS token: no token-0 side path, plain site masks
+        out = Tower(cfg, w, max_batch=8, compute=compute).encode_ids(ids).cpu().numpy()
+        cos = (out * ref).sum(1) / (np.linalg.norm(out, axis=1) * np.linalg.norm(ref, axis=1))
+        print(f"tiny-text {compute} min cos={cos.min():.5f}")
+        assert cos.min() > 0.99

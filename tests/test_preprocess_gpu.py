@@ -111,3 +111,37 @@ def test_bad_arguments():
     with pytest.raises(ValueError):
         preprocess_frames(np.zeros((1, 224, 224, 4), np.uint8))
     assert preprocess_frames(np.zeros((0, 224, 224, 3), np.uint8)).shape == (0, 3, 224, 224)
+
+
+def test_two_threads_two_streams_different_sizes():
+    """the resample scratch is per stream and outgrown blocks stay alive, so two host threads preprocessing
+    different (growing) frame sizes on their own streams - a CLIP extractor and a DINO filter side by side, as the
+    reference's thread pool would run them (unified_index.py:773) - must each get bit-exact results."""
+    import threading
+    from ivr_amd.preprocess import preprocess_frames
+    sizes = {0: [(120, 90), (360, 640), (300, 400), (720, 1280)], 1: [(640, 360), (200, 200), (1080, 1920), (90, 160)]}
+    modes = {0: "shortest_edge_crop", 1: "stretch"}
+    errors = []
+
+    def work(tid):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for rep in range(3):
+                    for (h, w) in sizes[tid]:
+                        n = 2 + (rep + tid) % 3
+                        frames = synth_frames(100 * tid + h + rep, n, h, w)
+                        out = preprocess_frames(frames, modes[tid], out_dtype=torch.float32)
+                        stream.synchronize()
+                        ref = P.preprocess(frames, modes[tid], C.CLIP_MEAN, C.CLIP_STD)
+                        if not np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)):
+                            errors.append((tid, rep, h, w))
+        except Exception as e:                       # pragma: no cover - reported below
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
