@@ -31,14 +31,19 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PMC_NAME = {"scan_groupmax": "scan_groupmax_kernel<1>", "scan16_groupmax": "scan16_groupmax_kernel<1>", "preprocess_emit": "emit_vec_kernel<bf16, 32>"}
+PMC_FILE = "r01_pmc_traffic.json"   # the committed PMC passes `traffic` is read from (tools/pmc_aggregate.py)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
 
 
-def cpu_baseline(cfg, weights, frames_u8, index_rows, queries, k, budget_s=20.0):
+def cpu_baseline(cfg, weights, index_rows, queries, k, budget_s=25.0):
     """The oracle (a port: the reference's own Python cannot travel) timed on this box's host
-    cores on a bounded sample of the same workload: the fp32 tower in batches of 32 (core.py:1558) and the exact
-    inner-product top-k over a slice of the index."""
+    cores.  Two parts, both reported:
+      * BASELINE.json configs[0] exactly: 1,000 synthetic 224x224 frames (default_rng(1234)) through the fp32 tower in
+        batches of 32 (core.py:1558) -> 1,000 x 512 rows -> 10 Gaussian queries (default_rng(91011)), exact top-10;
+        cut short (and said so) only if the embedding alone would exceed the time budget;
+      * the exact inner-product top-k over a 100,000-row slice of the benchmark's own index: the 1,000-row search of
+        configs[0] lasts microseconds, too short to quote a pairs/s figure from."""
     from oracle import preprocess_ref as P
     from oracle import search_ref as S
     from oracle import vit_ref as V
@@ -46,29 +51,111 @@ def cpu_baseline(cfg, weights, frames_u8, index_rows, queries, k, budget_s=20.0)
     # threads actually used: this process's CPU share (the box has more logical cores than a 1-GPU job may use)
     cores = min(len(os.sched_getaffinity(0)), 32)
     torch.set_num_threads(cores)
-    px = P.preprocess(frames_u8[:32], "identity", C.CLIP_MEAN, C.CLIP_STD)
-    V.vision_forward(cfg, weights, px[:8])                       # warm-up
-    done, t0 = 0, time.perf_counter()
-    while True:
-        emb = V.vision_forward(cfg, weights, px)
+    frames = np.random.default_rng(1234).integers(0, 256, (1000, 224, 224, 3), dtype=np.uint8)
+    V.vision_forward(cfg, weights, P.preprocess(frames[:8], "identity", C.CLIP_MEAN, C.CLIP_STD))      # warm-up
+    embs, done, t0 = [], 0, time.perf_counter()
+    while done < len(frames):
+        px = P.preprocess(frames[done:done + 32], "identity", C.CLIP_MEAN, C.CLIP_STD)
+        embs.append(V.vision_forward(cfg, weights, px))
         done += len(px)
-        if time.perf_counter() - t0 > budget_s * 0.75 or done >= 512:
+        if time.perf_counter() - t0 > budget_s:
             break
     t_embed = time.perf_counter() - t0
+    rows0 = np.concatenate(embs)
+    q0 = S.normalize_rows_core(np.random.default_rng(91011).standard_normal((10, rows0.shape[1]), dtype=np.float32)).astype(np.float32)
+    t1 = time.perf_counter()
+    for _ in range(20):
+        D0, I0 = S.flat_ip_search(rows0, q0, 10)
+    t_s0 = (time.perf_counter() - t1) / 20
     S.flat_ip_search(index_rows[:1000], queries, k)              # warm-up
     t1 = time.perf_counter()
     reps = 0
     while True:
         S.flat_ip_search(index_rows, queries, k)
         reps += 1
-        if time.perf_counter() - t1 > budget_s * 0.25 or reps >= 20:
+        if time.perf_counter() - t1 > 5.0 or reps >= 20:
             break
     t_search = (time.perf_counter() - t1) / reps
     return {"value": done / t_embed, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{done} frames of 224x224 through the fp32 oracle {cfg.name} in batches of 32 "
-                      f"({t_embed:.1f} s); exact IP top-{k} of {len(queries)} queries over {len(index_rows)} x "
-                      f"{index_rows.shape[1]} rows, {reps} repeats",
-            "pairs_per_s": len(index_rows) * len(queries) / t_search, "threads": torch.get_num_threads(), "emb_dim": int(emb.shape[1])}
+            "sample": f"configs[0]{' exactly' if done == len(frames) else ' cut at the time budget'}: {done} of 1000 frames of 224x224 "
+                      f"through the fp32 oracle {cfg.name} in batches of 32 ({t_embed:.1f} s), 10 queries top-10 over those "
+                      f"{len(rows0)} rows ({t_s0 * 1e6:.0f} us per search); pairs/s from the exact IP top-{k} of {len(queries)} queries "
+                      f"over a {len(index_rows)} x {index_rows.shape[1]} slice of the benchmark's index, {reps} repeats",
+            "pairs_per_s": len(index_rows) * len(queries) / t_search, "configs0_search_us": t_s0 * 1e6,
+            "configs0_top1_ids": [int(v) for v in I0[:, 0]], "threads": torch.get_num_threads(), "emb_dim": int(rows0.shape[1])}
+
+
+def side_configs(dev, weights_b32):
+    """The other BASELINE configs that fit one GPU, timed by this same process right after the headline (outside its timed
+    region): one GPU's shard of configs[2] (1.25M rows x 1000 queries), configs[3] at full size (8 feeds
+    of 1280x720 BGR -> rolling 5M-row index, hipGraph replay) and the configs[4] tower (ViT-L/14 bf16 / e4m3 modes)."""
+    from ivr_amd import config as C
+    from ivr_amd.index import FlatIPIndex
+    from ivr_amd.streaming import StreamingSession
+    from ivr_amd.tower import Tower
+    from ivr_amd.weights import make_weights
+    out = {}
+
+    def timed(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    g = torch.Generator(device=dev).manual_seed(5678)
+    rows = 5_000_000
+    index = FlatIPIndex(512, capacity=rows, device=dev.index)
+    for i in range(0, rows, 250_000):
+        index.add(torch.randn((250_000, 512), generator=g, device=dev), normalize=True)
+        if i + 250_000 == 1_250_000:                       # configs[2]: 10M rows over 8 GPUs = 1.25M rows per GPU, 1000 queries
+            q = torch.randn((1000, 512), generator=g, device=dev)
+            index.reserve_search(1000, 10)
+            for _ in range(2):
+                index.search_device(q, 10, normalize=True)
+            ms = timed(lambda: index.search_device(q, 10, normalize=True), 5)
+            out["configs2_one_shard"] = {"rows": 1_250_000, "queries": 1000, "k": 10, "search_ms": ms,
+                                         "pairs_per_s": 1_250_000 * 1000 / (ms * 1e-3)}
+    cfg = C.CLIP_VIT_B32
+    tower = Tower(cfg, weights_b32, max_batch=8, device=dev.index)
+    queries = torch.from_numpy(np.random.default_rng(91011).standard_normal((10, 512), dtype=np.float32))
+    frames = torch.randint(0, 256, (8, 720, 1280, 3), generator=g, device=dev, dtype=torch.uint8)
+    st = {"rows": rows, "feeds": 8, "frames_per_step": 8, "frame": "1280x720 BGR, stretch-resized on the GPU", "queries": 10, "k": 10}
+    for use_graph in (True, False):
+        sess = StreamingSession(tower, index, 8, 720, 1280, queries, k=10, mode="stretch", bgr=True, use_graph=use_graph)
+        for _ in range(5):
+            sess.step(frames)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            sess.step(frames)
+        torch.cuda.synchronize()
+        st["graph_replay_ms" if use_graph else "plain_launch_ms"] = (time.perf_counter() - t0) / 100 * 1e3
+    st["real_time_margin"] = (1000.0 / 30.0) / st["graph_replay_ms"]
+    out["configs3_streaming_step"] = st
+    del index, tower, sess
+    torch.cuda.empty_cache()
+    cfg = C.CLIP_VIT_L14
+    wl = make_weights(cfg, 12)
+    kpad = (3 * cfg.patch * cfg.patch + 63) // 64 * 64
+    patches = (torch.randn((512 * (cfg.tokens - 1), kpad), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    emb = torch.empty((512, cfg.embed_dim), dtype=torch.float32, device=dev)
+    l14 = {"frames_per_step": 512}
+    for compute in ("bf16", "fp8", "fp8_all"):
+        tw = Tower(cfg, wl, max_batch=512, compute=compute, device=dev.index)
+        for _ in range(2):
+            tw.encode_patches(patches, 512, out=emb)
+        ms = timed(lambda: tw.encode_patches(patches, 512, out=emb), 4)
+        l14[compute] = {"ms_per_step": ms, "frames_per_s": 512 / (ms * 1e-3)}
+        tw.close()
+        del tw
+        torch.cuda.empty_cache()
+    l14["note"] = ("encoder only (patch-major pixels resident); fp8 = fc1+fc2 in e4m3 + bf16 token-0 rows (1 - cos <= 1e-3), fp8_all = all "
+                   "four sites in e4m3 (1 - cos ~ 4e-3): tests/test_fp8_gpu.py, profiles/r02_fp8_error_budget.json")
+    out["configs4_tower_vit_l14"] = l14
+    return out
 
 
 def _free_port():
@@ -135,6 +222,7 @@ def main():
     ap.add_argument("--queries", type=int, default=10)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side configurations (configs[2] shard, configs[3], configs[4] tower)")
     ap.add_argument("--lanes", type=int, default=1, help="split each step's frames over this many HIP streams / towers")
     # the defaults are BASELINE.json configs[1] (the metric's configuration); the two flags below select the
     # configs[4]-shaped variant (ViT-L/14, fp8 GEMMs, 768-d rows) as an additional measurement, never the headline
@@ -265,7 +353,7 @@ def main():
         # profile was taken at another batch size
         pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 pmc = json.load(f)
         except OSError:
             pass
@@ -328,8 +416,17 @@ def main():
         out["recall_at_10"] = float(np.mean([len(set(Il[q]) & set(Ir[q])) / k for q in range(Q)]))
         out["ids_exact"] = bool(np.array_equal(Il, Ir))
         out["max_abs_score_err"] = float(np.abs(Dl - Dr).max())
+        for key in ("roofline", "roofline_search", "roofline_preprocess"):
+            if out.get(key):
+                out[key]["traffic_source"] = (f"profiles/{PMC_FILE} (rocprofv3 --pmc passes of this same command, tools/pmc_aggregate.py; "
+                                              "not re-measured in this run)") if pmc_ok else None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, weights, frame_tiles[0][:32].cpu().numpy(), Xh[:100_000], qn, k)
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, Xh[:100_000], qn, k)
+        if world == 1 and headline and not args.no_extra:
+            # free the headline's buffers first: the streaming index alone is 15 GB
+            del frame_tiles, patches, emb, index, sharded, towers, tower, Xh
+            torch.cuda.empty_cache()
+            out["extra"] = side_configs(dev, weights)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -120,6 +120,20 @@ __device__ __forceinline__ float ivr_wave_sum(float v) {
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+template <int CTRL>
+__device__ __forceinline__ uint32_t ivr_dpp_u(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t ivr_wave_max_u32(uint32_t v) {
+    v = max(v, ivr_dpp_u<0xB1>(v));
+    v = max(v, ivr_dpp_u<0x4E>(v));
+    v = max(v, ivr_dpp_u<0x141>(v));
+    v = max(v, ivr_dpp_u<0x140>(v));
+    auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = max((uint32_t)a[0], (uint32_t)a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return max((uint32_t)b[0], (uint32_t)b[1]);
+}
 __device__ __forceinline__ float ivr_wave_max(float v) {
     v = fmaxf(v, ivr_dpp<0xB1>(v));
     v = fmaxf(v, ivr_dpp<0x4E>(v));

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict_
                                                         int64_t row_start, int64_t n, int d, int dp4,
                                                         int normalize, int32_t *__restrict__ nonfinite,
                                                         const int64_t *__restrict__ start_dev, uint4 *__restrict__ dst16,
-                                                        uint4 *__restrict__ dst16lo, unsigned int *__restrict__ maxnorm_bits) {
+                                                        uint4 *__restrict__ dst16lo, unsigned int *__restrict__ maxnorm_bits,
+                                                        float *__restrict__ rownorm, int zero_fill) {
     if (start_dev) row_start = *start_dev;          // ring cursor kept in HBM so a captured graph can replay it
     const int lane = threadIdx.x & 63;
     const int64_t tile0 = row_start >> 4;
@@ -65,16 +66,25 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict_
     const int kchunks = dp4 >> 2;
     float ss = 0.f;
     int bad = 0;
-    if (normalize || nonfinite || maxnorm_bits) {
-        for (int kc = 0; kc < kchunks; ++kc) {
-            const int k0 = kc * 16 + qd * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid && k0 < d) v = load_quad(srow, k0, d, vec && k0 + 3 < d);
-            ss = fmaf(v.x, v.x, ss);
-            ss = fmaf(v.y, v.y, ss);
-            ss = fmaf(v.z, v.z, ss);
-            ss = fmaf(v.w, v.w, ss);
-            bad += !isfinite(v.x) + !isfinite(v.y) + !isfinite(v.z) + !isfinite(v.w);
+    if (normalize || nonfinite || maxnorm_bits || rownorm) {
+        // eight chunks per trip, all loads issued before the first use: a query batch is a handful of rows, so this kernel is
+        // a latency chain (32 dependent trips of ~0.4 us at d = 512 before); the sum keeps its ascending-k order
+        for (int kc0 = 0; kc0 < kchunks; kc0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k0 = (kc0 + u) * 16 + qd * 4;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid && kc0 + u < kchunks && k0 < d) v[u] = load_quad(srow, k0, d, vec && k0 + 3 < d);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ss = fmaf(v[u].x, v[u].x, ss);
+                ss = fmaf(v[u].y, v[u].y, ss);
+                ss = fmaf(v[u].z, v[u].z, ss);
+                ss = fmaf(v[u].w, v[u].w, ss);
+                bad += !isfinite(v[u].x) + !isfinite(v[u].y) + !isfinite(v[u].z) + !isfinite(v[u].w);
+            }
         }
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
@@ -96,17 +106,32 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict_
         const unsigned int bits = __float_as_uint(stored);
         if (lane == 0 && bits > *maxnorm_bits) atomicMax(maxnorm_bits, bits);
     }
+    // query tiles: an upper bound of the stored row's norm for the error bound of the bf16 candidate scan (1 up to rounding once
+    // normalised, as for the index rows above)
+    if (rownorm && valid && qd == 0) rownorm[row - row_start] = normalize ? (ss > 0.f ? 1.000001f : 0.f) : sqrtf(ss);
     float4 *out = reinterpret_cast<float4 *>(dst) + tile * (int64_t)dp4 * 16 + lane;
     const int pieces = (kchunks + 1) >> 1;
-    for (int kb = 0; kb < pieces; ++kb) {
-        float4 v[2];
+    const bool store = valid || zero_fill;          // query tiles: the padding rows of the last tile are written as zeros
+    for (int kb0 = 0; kb0 < pieces; kb0 += 4) {
+      float4 vv[4][2];
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int kc = 2 * kb + u, k0 = kc * 16 + qd * 4;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid && kc < kchunks) {
-                if (k0 < d) v[u] = load_quad(srow, k0, d, vec && k0 + 3 < d);
-                if (normalize) {
+            const int kc = 2 * (kb0 + b4) + u, k0 = kc * 16 + qd * 4;
+            vv[b4][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && kc < kchunks && k0 < d) vv[b4][u] = load_quad(srow, k0, d, vec && k0 + 3 < d);
+        }
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4) {
+        const int kb = kb0 + b4;
+        if (kb >= pieces) break;
+        float4 (&v)[2] = vv[b4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kc = 2 * kb + u;
+            if (store && kc < kchunks) {
+                if (valid && normalize) {
                     v[u].x /= nrm;
                     v[u].y /= nrm;
                     v[u].z /= nrm;
@@ -115,7 +140,7 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict_
                 out[kc * 64] = v[u];
             }
         }
-        if (dst16 && valid) {
+        if (dst16 && store) {
             uint4 hi;
             hi.x = ivr_pack_bf16x2(v[0].x, v[0].y);
             hi.y = ivr_pack_bf16x2(v[0].z, v[0].w);
@@ -134,6 +159,7 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict_
                 dst16lo[(tile * pieces + kb) * 64 + lane] = lo;
             }
         }
+      }
     }
 }
 
@@ -357,36 +383,26 @@ __global__ __launch_bounds__(512) void scan16_groupmax_kernel(const uint4 *__res
     }
 }
 
-// one thread per query of the chunk: does the (kp+1)-th approximate group maximum + error bound stay strictly below the k-th
-// exact score?  ok[q] = 1 keeps the fast result; otherwise the query's tile is flagged for the exact pass.
-__global__ __launch_bounds__(64) void verify_candidates_kernel(const float *__restrict__ gmax, int64_t mstride, const uint32_t *__restrict__ sel,
-                                                               int ksel2, int kp, const float *__restrict__ D, int k, int nq,
-                                                               const float *__restrict__ qtiled, int dp4, float rel_eps,
-                                                               const unsigned int *__restrict__ maxnorm_bits, int *__restrict__ ok,
-                                                               int *__restrict__ tile_flag) {
-    const int q = threadIdx.x;
-    if (q < 4) tile_flag[q] = 0;                   // this kernel owns the flags of its chunk: reset, then raise
-    __syncthreads();
-    if (q >= nq) return;
-    const uint32_t g = sel[(int64_t)q * ksel2 + kp];
-    int good = 1;
-    if (g != 0xFFFFFFFFu) {                       // there IS an excluded group
-        // |q| from the tiled float32 query (query q of tile q >> 4: float4 number kq * 16 + (q & 15) of the tile)
-        const float4 *qt = reinterpret_cast<const float4 *>(qtiled) + (int64_t)(q >> 4) * dp4 * 16 + (q & 15);
-        float ss = 0.f;
-        for (int kq = 0; kq < dp4; ++kq) {
-            const float4 v = qt[kq * 16];
-            ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
-        }
-        const float bound = gmax[(int64_t)q * mstride + g] + rel_eps * sqrtf(ss) * __uint_as_float(*maxnorm_bits);
-        const float kth = D[(int64_t)q * k + (k - 1)];
-        good = bound < kth;                        // false for NaN / inf bounds too
-    }
-    ok[q] = good;
-    if (!good) atomicOr(&tile_flag[q >> 4], 1);
-}
+// Verification of the bf16 candidate scan, done by the final selection of each query (select_topk_kernel<SrcKeys, OUT_DI>): does
+// the (kp+1)-th approximate group maximum + error bound stay strictly below the k-th exact score?  ok[q] = 1 keeps the fast
+// result; otherwise the query's tile is flagged for the exact pass.  tile_flag[0..3] is reset by the group selection launched
+// before (same stream), so the blocks of the final selection only ever raise flags.
+struct VerifyArgs {
+    const float *gmax = nullptr;          // approximate group maxima [query column][mstride]
+    int64_t mstride = 0;
+    const uint32_t *sel = nullptr;        // [nq][ksel2]: selected groups, entry kp = the first excluded one
+    int ksel2 = 0, kp = 0;
+    const float *qnorm = nullptr;         // upper bound of each query's stored norm (tile_rows_kernel)
+    float rel_eps = 0.f;
+    const unsigned int *maxnorm_bits = nullptr;
+    int *ok = nullptr;                    // NULL = no verification in this launch
+    int *tile_flag = nullptr;
+};
 
-// pass 3: one wave per (query, selected group).  cand[q][j*64 + row] = key(score, row id)
+// pass 3: one wave per (query, selected group, 16-row tile).  cand[q][j*64 + row] = key(score, row id).
+// A tile's accumulator sees exactly the MFMA sequence it sees in score_group (ascending K, x y z w per chunk), so the scores are
+// bit-identical to pass 1; splitting the group over four waves and keeping 16 KiB of the tile in flight per wave is what makes
+// this pass short: it is a latency chain of k x 64 rows per query, not a bandwidth problem.
 __global__ __launch_bounds__(256) void rescore_groups_kernel(const float *__restrict__ data,
                                                              const float *__restrict__ qtiled, int dp4,
                                                              int64_t ntotal, const uint32_t *__restrict__ sel,
@@ -394,32 +410,52 @@ __global__ __launch_bounds__(256) void rescore_groups_kernel(const float *__rest
                                                              const int *__restrict__ skip) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= (int64_t)nq * ksel) return;
-    const int q = (int)(w / ksel), j = (int)(w % ksel);
+    if (w >= (int64_t)nq * ksel * 4) return;
+    const int t = (int)(w & 3);
+    const int64_t qj = w >> 2;
+    const int q = (int)(qj / ksel), j = (int)(qj % ksel);
     if (skip && skip[q]) return;
     const uint32_t g = sel[(int64_t)q * sel_stride + j];
-    uint64_t *out = cand + ((int64_t)q * ksel + j) * kGroupRows;
+    uint64_t *out = cand + ((int64_t)q * ksel + j) * kGroupRows + t * 16;
     if (g == 0xFFFFFFFFu) {   // fewer groups than k
-        out[lane] = 0;
+        if (lane < 16) out[lane] = 0;
         return;
     }
-    const int per_tile = dp4 * 16;
+    const int per_tile = dp4 * 16, kchunks = dp4 >> 2;
     const float4 *b = reinterpret_cast<const float4 *>(qtiled) + (int64_t)(q >> 4) * per_tile + lane;
-    auto bload = [&](int, int kc) { return b[kc * 64]; };
-    f32x4 acc[1][4];
-    const float4 *a = reinterpret_cast<const float4 *>(data) + (int64_t)g * 4 * per_tile + lane;
-    score_group<1>(a, per_tile, dp4 >> 2, bload, acc);
+    const float4 *a = reinterpret_cast<const float4 *>(data) + ((int64_t)g * 4 + t) * per_tile + lane;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int kc = 0;
+    for (; kc + 16 <= kchunks; kc += 16) {
+        float4 av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) av[u] = a[(kc + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bv[u] = b[(kc + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+        }
+    }
+    for (; kc < kchunks; ++kc) {
+        const float4 av = a[kc * 64], bv = b[kc * 64];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    }
     if ((lane & 15) == (q & 15)) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rl = t * 16 + (lane >> 4) * 4 + r;
-                const int64_t row = (int64_t)g * kGroupRows + rl;
-                uint64_t key = 0;
-                if (row < ntotal) key = ((uint64_t)ivr_f2ord(acc[0][t][r]) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)row);
-                out[rl] = key;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int rl = (lane >> 4) * 4 + r;
+            const int64_t row = (int64_t)g * kGroupRows + t * 16 + rl;
+            uint64_t key = 0;
+            if (row < ntotal) key = ((uint64_t)ivr_f2ord(acc[r]) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)row);
+            out[rl] = key;
+        }
     }
 }
 
@@ -462,7 +498,9 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
                                                                   uint32_t *__restrict__ out_groups,
                                                                   float *__restrict__ D, int64_t *__restrict__ I,
                                                                   const int64_t *__restrict__ I_parts,
-                                                                  const int *__restrict__ skip = nullptr) {
+                                                                  const int *__restrict__ skip = nullptr, VerifyArgs vf = VerifyArgs(),
+                                                                  int *__restrict__ reset_flags = nullptr) {
+    if (reset_flags && blockIdx.x == 0 && threadIdx.x < 4) reset_flags[threadIdx.x] = 0;
     if (skip && skip[blockIdx.x]) return;          // whole block: this query kept its fast-path result
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix, s_mask;
@@ -505,54 +543,36 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
     __syncthreads();
     const unsigned int keff = min((unsigned int)k, s_valid);
     __shared__ uint64_t wmax[kSelThreads / 64];
-    // Long candidate lists (one key per 64 stored rows): first cut the list down.  The keff-th largest of the per-thread
-    // maxima, T, is a lower bound of the keff-th largest key (keff threads each hold a key >= T), so only keys >= T can be
-    // selected - typically a few times keff of them.  Wave 0 finds T and then the answer among the survivors without a
-    // single workgroup barrier per round; the rounds below (two barriers each, 16 waves) remain the fallback when too many
-    // keys survive (ties in bulk).
+    // Small k (the reference asks for 10..50; here up to 16 keys per wave): no serial extraction rounds.
+    //  (1) every thread's largest key; (2) a lower bound T of the keff-th largest key: each wave removes the largest of its
+    //  per-thread maxima r = ceil(keff / #waves) times (one DPP wave-max of the 32-bit score per round; equal scores leave
+    //  together) and T is the smallest score removed last by any wave - every wave then holds >= r keys >= T, the block >= keff;
+    //  (3) the keys >= T are collected, typically a few times keff of them; (4) each survivor counts the survivors above it:
+    //  that is its rank (keys are unique).  Four barriers in all; the radix / extraction paths below remain the fallback when
+    //  too many keys survive (scores tied in bulk).
     __shared__ uint64_t surv[kSelThreads];
     __shared__ unsigned int s_nsurv;
+    __shared__ uint32_t wlow[kSelThreads / 64];
     bool done = false;
-    if (nthr == kSelThreads && keff > 1 && keff <= 64) {
+    const unsigned int nwv = (unsigned int)nthr >> 6;
+    const unsigned int rounds = (keff + nwv - 1) / nwv;
+    if (keff >= 1 && rounds <= 16) {
         uint64_t tm = 0;
         for_each_key([&](uint64_t key) { tm = key > tm ? key : tm; });
-        surv[tid] = tm;
+        uint32_t cur = (uint32_t)(tm >> 32), last = 0;
+        for (unsigned int it = 0; it < rounds; ++it) {
+            last = ivr_wave_max_u32(cur);
+            if (cur == last) cur = 0;
+        }
+        if ((tid & 63) == 0) wlow[tid >> 6] = last;
         if (tid == 0) s_nsurv = 0;
         __syncthreads();
-        auto wave_max64 = [](uint64_t v) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), o, 64), lo = __shfl_xor((uint32_t)v, o, 64);
-                const uint64_t other = ((uint64_t)hi << 32) | lo;
-                v = other > v ? other : v;
-            }
-            return v;
-        };
-        constexpr int PER = kSelThreads / 64;          // values per lane of wave 0
-        if (tid < 64) {
-            uint64_t v[PER];
-#pragma unroll
-            for (int j = 0; j < PER; ++j) v[j] = surv[j * 64 + tid];
-            uint64_t T = 0;
-            for (unsigned int it = 0; it < keff; ++it) {
-                uint64_t m = 0;
-#pragma unroll
-                for (int j = 0; j < PER; ++j) m = v[j] > m ? v[j] : m;
-                T = wave_max64(m);
-                if (m == T) {                      // unique keys: one lane, one slot (0 only when fewer than keff threads hold keys)
-#pragma unroll
-                    for (int j = 0; j < PER; ++j)
-                        if (v[j] == T) v[j] = 0;
-                }
-            }
-            if (tid == 0) wmax[0] = T;
-        }
-        __syncthreads();
-        const uint64_t T = wmax[0];
-        __syncthreads();                           // surv[] is reused below
-        if (T != 0) {
+        uint32_t T = 0xFFFFFFFFu;
+        for (unsigned int w = 0; w < nwv; ++w) T = min(T, wlow[w]);
+        if (T != 0) {                              // 0: some wave ran out of keys - the fallback handles short lists
+            const uint64_t T64 = (uint64_t)T << 32;
             for_each_key([&](uint64_t key) {
-                if (key >= T) {
+                if (key >= T64) {
                     const unsigned int slot = atomicAdd(&s_nsurv, 1u);
                     if (slot < (unsigned int)kSelThreads) surv[slot] = key;
                 }
@@ -560,25 +580,14 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
         }
         __syncthreads();
         const unsigned int ns = s_nsurv;
-        if (T != 0 && ns <= (unsigned int)kSelThreads) {
-            if (tid < 64) {
-                uint64_t v[PER];
-#pragma unroll
-                for (int j = 0; j < PER; ++j) v[j] = (unsigned int)(j * 64 + tid) < ns ? surv[j * 64 + tid] : 0;
-                for (unsigned int it = 0; it < keff; ++it) {
-                    uint64_t m = 0;
-#pragma unroll
-                    for (int j = 0; j < PER; ++j) m = v[j] > m ? v[j] : m;
-                    const uint64_t gm = wave_max64(m);
-                    if (tid == 0) sorted[it] = gm;
-                    if (m == gm) {
-#pragma unroll
-                        for (int j = 0; j < PER; ++j)
-                            if (v[j] == gm) v[j] = 0;
-                    }
-                }
+        if (T != 0 && ns <= (unsigned int)nthr) {   // uniform: T and ns come from shared memory; ns >= keff by construction
+            if ((unsigned int)tid < ns) {
+                const uint64_t mine = surv[tid];
+                unsigned int rank = 0;
+                for (unsigned int j2 = 0; j2 < ns; ++j2) rank += surv[j2] > mine;
+                if (rank < keff) sorted[rank] = mine;
             }
-            done = true;                          // uniform: T and ns come from shared memory
+            done = true;
             __syncthreads();
         }
     }
@@ -698,6 +707,17 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
             I[(int64_t)q * k + j] = id;
         }
     }
+    if (OUT == OUT_DI && vf.ok && tid == 0) {
+        const uint32_t g = vf.sel[(int64_t)q * vf.ksel2 + vf.kp];
+        int good = 1;
+        if (g != 0xFFFFFFFFu) {                       // there IS an excluded group
+            const float bound = vf.gmax[(int64_t)q * vf.mstride + g] + vf.rel_eps * vf.qnorm[q] * __uint_as_float(*vf.maxnorm_bits);
+            const float kth = (int)keff >= k ? ivr_ord2f((uint32_t)(sorted[k - 1] >> 32)) : -FLT_MAX;
+            good = bound < kth;                        // false for NaN / inf bounds too
+        }
+        vf.ok[q] = good;
+        if (!good) atomicOr(&vf.tile_flag[q >> 4], 1);
+    }
 }
 
 }  // namespace
@@ -713,6 +733,7 @@ struct ivr_index {
     std::mutex mu;
     // search workspace (grow-only)
     float *qtiled = nullptr;         // [qtiles][dp4][16][4]
+    float *qnorm = nullptr;          // [qtiles*16] upper bound of each tiled query's norm (bf16 candidate scan verification)
     int qtiles_cap = 0;
     float *gmax = nullptr;           // [qcols][mstride]
     int64_t gmax_floats = 0;
@@ -768,9 +789,10 @@ int launch_tile_rows(ivr_index *x, float *dst, const float *src, int64_t start, 
     const unsigned grid = (unsigned)ivr_ceil_div(ntiles, 4);
     const bool rows = dst == x->data;
     IvrProf prof("tile_rows", s, (double)n * (x->d + x->dp) * 4 + (x->scan16 ? (double)n * x->pieces * 64 * (rows ? 1 : 2) : 0.0));
+    // query tiles: the padding rows of the last tile are zero-filled by the kernel itself (no memset in front of it)
     hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, src, dst, start, n, x->d, x->dp4, normalize, nonfinite, start_dev,
                        x->scan16 ? (rows ? x->data16 : x->q16hi) : (uint4 *)nullptr, x->scan16 && !rows ? x->q16lo : (uint4 *)nullptr,
-                       x->scan16 && rows ? x->maxnorm : (unsigned int *)nullptr);
+                       x->scan16 && rows ? x->maxnorm : (unsigned int *)nullptr, rows ? (float *)nullptr : x->qnorm, rows ? 0 : 1);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
@@ -786,11 +808,15 @@ int reserve_search(ivr_index *x, int nq, int k) {
     const int qtiles = (int)ivr_ceil_div(nq, 16);
     if (qtiles > x->qtiles_cap) {
         if (x->qtiles_cap) IVR_HIP(hipFree(x->qtiled));
+        if (x->qnorm) IVR_HIP(hipFree(x->qnorm));
         x->qtiled = nullptr;
+        x->qnorm = nullptr;
         x->qtiles_cap = 0;
         const int want = std::max(qtiles, 4);
         IVR_HIP(hipMalloc(&x->qtiled, (size_t)want * 16 * x->dp * 4));
         IVR_HIP(hipMemset(x->qtiled, 0, (size_t)want * 16 * x->dp * 4));
+        IVR_HIP(hipMalloc(&x->qnorm, (size_t)want * 16 * 4));
+        IVR_HIP(hipMemset(x->qnorm, 0, (size_t)want * 16 * 4));
         if (x->scan16) {
             if (x->q16hi) IVR_HIP(hipFree(x->q16hi));
             if (x->q16lo) IVR_HIP(hipFree(x->q16lo));
@@ -895,6 +921,7 @@ int ivr_index_destroy(ivr_index *x) {
     if (!x) return IVR_OK;
     if (x->data) (void)hipFree(x->data);
     if (x->qtiled) (void)hipFree(x->qtiled);
+    if (x->qnorm) (void)hipFree(x->qnorm);
     if (x->gmax) (void)hipFree(x->gmax);
     if (x->sel) (void)hipFree(x->sel);
     if (x->cand) (void)hipFree(x->cand);
@@ -1000,8 +1027,6 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
     const int64_t mstride = ivr_round_up(x->cap / kGroupRows, 64);
     // queries -> tiled layout (normalised on the way when asked: N2 on the query side, core.py:875)
     {
-        const int64_t ntiles = ivr_ceil_div(nq, 16);
-        IVR_HIP(hipMemsetAsync(x->qtiled, 0, (size_t)ntiles * 16 * x->dp * 4, s));
         rc = launch_tile_rows(x, x->qtiled, q, 0, nq, normalize_q, nullptr, s);
         if (rc != IVR_OK) return rc;
     }
@@ -1037,7 +1062,7 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         // rescore reads query tile (q >> 4) relative to the chunk's first tile
         {
             IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4);
-            hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)ivr_ceil_div(waves, 4)), dim3(256), 0, s, x->data, qtile, x->dp4,
+            hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)waves), dim3(256), 0, s, x->data, qtile, x->dp4,
                                x->ntotal, x->sel, ksel, ksel, nqc, x->cand, skip);
         }
         IVR_LAUNCH_CHECK();
@@ -1071,26 +1096,35 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         {
             IvrProf prof("select_groups", s, (double)nqc * ngroups * 4);
             hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(sel_threads(ngroups)), 0, s, sg, 0, ksel2,
-                               (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr, (const int *)nullptr);
+                               (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr, (const int *)nullptr,
+                               VerifyArgs(), tile_flag);
         }
         IVR_LAUNCH_CHECK();
         const int64_t waves = (int64_t)nqc * kp;
         {
             IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4);
-            hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)ivr_ceil_div(waves, 4)), dim3(256), 0, s, x->data, qtile, x->dp4,
+            hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)waves), dim3(256), 0, s, x->data, qtile, x->dp4,
                                x->ntotal, x->sel, ksel2, kp, nqc, x->cand, (const int *)nullptr);
         }
         IVR_LAUNCH_CHECK();
         {
             SrcKeys sk{x->cand, (int64_t)kp * kGroupRows};
             IvrProf prof("select_final", s, (double)waves * kGroupRows * 8);
+            VerifyArgs vf;
+            vf.gmax = x->gmax;
+            vf.mstride = mstride;
+            vf.sel = x->sel;
+            vf.ksel2 = ksel2;
+            vf.kp = kp;
+            vf.qnorm = x->qnorm + q0;
+            vf.rel_eps = rel_eps;
+            vf.maxnorm_bits = x->maxnorm;
+            vf.ok = ok;
+            vf.tile_flag = tile_flag;
             hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(sel_threads((int64_t)kp * kGroupRows)), 0, s, sk, 0, k,
                                id_base, (uint32_t *)nullptr, D + (int64_t)q0 * k, I + (int64_t)q0 * k, (const int64_t *)nullptr,
-                               (const int *)nullptr);
+                               (const int *)nullptr, vf, (int *)nullptr);
         }
-        IVR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(verify_candidates_kernel, dim3(1), dim3(64), 0, s, x->gmax, mstride, x->sel, ksel2, kp, D + (int64_t)q0 * k, k, nqc,
-                           qtile, x->dp4, rel_eps, x->maxnorm, ok, tile_flag);
         IVR_LAUNCH_CHECK();
         // exact pass for the queries whose check failed: every kernel below exits at once when nothing is flagged
         rc = exact_pass(qtile, nqc, qt, q0, tile_flag, ok);

@@ -88,6 +88,11 @@ def main():
         L = vcfg.layers
         for lo, hi in ((0, L // 4), (0, L // 2), (L // 2, L), (3 * L // 4, L)):
             run(f"e4m3 all sites, layers [{lo},{hi}) / act scale row", QR.QuantSpec(QR.SITES, fp8_layers=range(lo, hi), act_scale="row"))
+    # the bf16 side path for the token-0 rows of the MLP sites (what the kernels implement: tower.hip run_layers)
+    for sub in (("fc1",), ("fc2",), ("fc1", "fc2"), QR.SITES):
+        spec = QR.QuantSpec(sub, keep_rows=(0,))
+        spec.keep_sites = {"fc1", "fc2"}
+        run(f"e4m3 {'+'.join(sub)} / token-0 rows of fc1, fc2 in bf16", spec)
     out = {"tower": vcfg.name, "frames": args.frames, "image_queries": args.image_queries, "text_queries": args.text_queries,
            "bound": "north_star: |score - f32 score| <= 1e-3", "rows": rows,
            "method": "oracle/quant_ref.py: operand rounding emulated on the CPU, float32 accumulation"}
