@@ -346,6 +346,24 @@ def main():
         elapsed = float(t.item())
     prof = _ffi.profile_read(local_rank)
     search_ms = sum(a.elapsed_time(b) for a, b in zip(ev_s0, ev_s1)) / max(1, len(ev_s0))
+    # the search alone, 50 times back to back with no per-kernel events, then 10 times with every launch of its tail
+    # bracketed (profile level 2): the breakdown costs a few microseconds per event pair, so it stays out of the timed region
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        sharded.search(queries, k, normalize=True)
+    e1.record()
+    torch.cuda.synchronize()
+    search_alone_ms = e0.elapsed_time(e1) / 50
+    _ffi.profile_reset(local_rank)
+    _ffi.profile_enable(2, local_rank)
+    for _ in range(10):
+        sharded.search(queries, k, normalize=True)
+    torch.cuda.synchronize()
+    _ffi.profile_enable(False, local_rank)
+    search_kernels_us = {n: v["ms"] / v["launches"] * 1e3 for n, v in sorted(_ffi.profile_read(local_rank).items())}
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         frames_total = B * args.steps * world
@@ -392,6 +410,9 @@ def main():
                        "frames_per_step_per_gpu": B, "frames_total": frames_total, "index_rows_per_gpu": N, "queries": Q, "k": k,
                        "parallelism": f"{world} x (frames + index rows sharded per GPU); one all-gather of (score,id) + merge"},
             "pairs_per_s": N * world * Q / (search_ms * 1e-3), "search_ms_per_step": search_ms,
+            "search_alone": {"ms": search_alone_ms, "pairs_per_s": N * world * Q / (search_alone_ms * 1e-3),
+                             "note": "50 searches back to back outside the timed region, no per-kernel events",
+                             "per_launch_us_with_events": search_kernels_us},
             "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": gemm_tf / mfma_peak,
                          "traffic": traffic(*[k for k in pmc if k.startswith(("gemm_big_kernel<bf16", "gemm_kernel<bf16"))]),
                          "kernel": ("gemm_big_kernel<bf16> / gemm_kernel<bf16>" if args.compute == "bf16" else "gemm_big8_kernel (e4m3 sites) + the bf16 GEMMs of the other sites, patch embedding and projection")

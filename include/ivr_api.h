@@ -61,9 +61,12 @@ int ivr_device_info(ivr_ctx *ctx, int *cu_count, int64_t *hbm_bytes, char *arch,
 
 /* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the launch stream ---------------
  * No counterpart in the reference (its only profiler is the wall-clock PerformanceMonitor.timer,
- * utils.py:2481).  When enabled every kernel launch is bracketed by two events; ivr_profile_json
- * synchronises on them and writes {"kernel": {"launches", "ms", "work"}} where work is the launch's
- * algorithmic bytes (HBM-bound kernels) or FLOP (MFMA-bound kernels). */
+ * utils.py:2481).  on = 1 brackets every launch of the kernels that carry a step (GEMMs, LayerNorm,
+ * attention, index scans, preprocess emit) with two events; on = 2 also the short launches of the search
+ * tail and the index append (an event pair costs microseconds on the stream: too much to leave around
+ * 5-microsecond kernels inside a timed region).  ivr_profile_json synchronises on the events and writes
+ * {"kernel": {"launches", "ms", "work"}} where work is the launch's algorithmic bytes (HBM-bound kernels)
+ * or FLOP (MFMA-bound kernels). */
 int ivr_profile_enable(ivr_ctx *ctx, int on);
 int ivr_profile_reset(ivr_ctx *ctx);
 int ivr_profile_json(ivr_ctx *ctx, char *buf /*HOST*/, int len);

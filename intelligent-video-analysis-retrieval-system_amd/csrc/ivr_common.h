@@ -57,13 +57,16 @@ int ivr_func_max_lds(const void *fn, int bytes);
 
 // Opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline figures).
 // `work` is the launch's algorithmic work: bytes for HBM-bound kernels, FLOP for MFMA-bound ones.
-bool ivr_prof_on();
+// Level 1 (ivr_profile_enable(ctx, 1)) brackets the kernels that carry the step - GEMMs, LayerNorm, attention, the index scans,
+// the preprocess emit; level 2 also the short launches of the search tail and the index append (`minor`): an event pair costs a few
+// microseconds ON the stream, which is nothing beside a GEMM and a quarter of a 0.28 ms search.
+int ivr_prof_level();
 void ivr_prof_begin(const char *name, hipStream_t s, double work);
 void ivr_prof_end(hipStream_t s);
 struct IvrProf {
     hipStream_t s;
     bool on;
-    IvrProf(const char *name, hipStream_t st, double work) : s(st), on(ivr_prof_on()) {
+    IvrProf(const char *name, hipStream_t st, double work, bool minor = false) : s(st), on(ivr_prof_level() >= (minor ? 2 : 1)) {
         if (on) ivr_prof_begin(name, s, work);
     }
     ~IvrProf() {

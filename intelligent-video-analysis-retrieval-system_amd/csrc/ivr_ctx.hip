@@ -65,7 +65,7 @@ struct ProfEntry {
 };
 struct Prof {
     std::mutex mu;
-    std::atomic<bool> on{false};
+    std::atomic<int> level{0};
     std::vector<ProfEntry> entries;
     std::vector<hipEvent_t> pool;
 };
@@ -85,7 +85,7 @@ hipEvent_t prof_event(Prof &p) {
 }
 }  // namespace
 
-bool ivr_prof_on() { return prof().on.load(std::memory_order_relaxed); }
+int ivr_prof_level() { return prof().level.load(std::memory_order_relaxed); }
 
 void ivr_prof_begin(const char *name, hipStream_t s, double work) {
     Prof &p = prof();
@@ -104,7 +104,7 @@ void ivr_prof_end(hipStream_t s) {
 extern "C" {
 
 int ivr_profile_enable(ivr_ctx *, int on) {
-    prof().on.store(on != 0);
+    prof().level.store(on < 0 ? 0 : on);
     return IVR_OK;
 }
 

@@ -788,7 +788,7 @@ int launch_tile_rows(ivr_index *x, float *dst, const float *src, int64_t start, 
     const int64_t ntiles = max_tiles ? max_tiles : ((start + n + 15) >> 4) - (start >> 4);
     const unsigned grid = (unsigned)ivr_ceil_div(ntiles, 4);
     const bool rows = dst == x->data;
-    IvrProf prof("tile_rows", s, (double)n * (x->d + x->dp) * 4 + (x->scan16 ? (double)n * x->pieces * 64 * (rows ? 1 : 2) : 0.0));
+    IvrProf prof("tile_rows", s, (double)n * (x->d + x->dp) * 4 + (x->scan16 ? (double)n * x->pieces * 64 * (rows ? 1 : 2) : 0.0), true);
     // query tiles: the padding rows of the last tile are zero-filled by the kernel itself (no memset in front of it)
     hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, src, dst, start, n, x->d, x->dp4, normalize, nonfinite, start_dev,
                        x->scan16 ? (rows ? x->data16 : x->q16hi) : (uint4 *)nullptr, x->scan16 && !rows ? x->q16lo : (uint4 *)nullptr,
@@ -862,7 +862,8 @@ void launch_scan(ivr_index *x, const float *qt, int64_t ngroups, int64_t mstride
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scan_groupmax_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
     // algorithmic bytes: every stored row once + the query tile + one maximum per (group, query)
-    IvrProf prof("scan_groupmax", s, (double)x->ntotal * x->dp * 4 + (double)QT * 16 * x->dp * 4 + (double)ngroups * QT * 16 * 4);
+    IvrProf prof("scan_groupmax", s, (double)x->ntotal * x->dp * 4 + (double)QT * 16 * x->dp * 4 + (double)ngroups * QT * 16 * 4,
+                 tile_flag != nullptr);      // behind the bf16 candidate scan it is the predicated fallback and normally exits at once
     hipLaunchKernelGGL(scan_groupmax_kernel<QT>, dim3((unsigned)grid), dim3(threads), lds, s, x->data, qt, x->dp4, ngroups,
                        x->ntotal, x->gmax, mstride, tile_flag);
 }
@@ -1053,7 +1054,7 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         }
         SrcGroupMax sg{x->gmax, mstride, ngroups};
         {
-            IvrProf prof("select_groups", s, (double)nqc * ngroups * 4);
+            IvrProf prof("select_groups", s, (double)nqc * ngroups * 4, true);
             hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(sel_threads(ngroups)), 0, s, sg, 0, ksel,
                                (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr, skip);
         }
@@ -1061,13 +1062,13 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         const int64_t waves = (int64_t)nqc * ksel;
         // rescore reads query tile (q >> 4) relative to the chunk's first tile
         {
-            IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4);
+            IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4, true);
             hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)waves), dim3(256), 0, s, x->data, qtile, x->dp4,
                                x->ntotal, x->sel, ksel, ksel, nqc, x->cand, skip);
         }
         IVR_LAUNCH_CHECK();
         SrcKeys sk{x->cand, (int64_t)ksel * kGroupRows};
-        IvrProf prof("select_final", s, (double)waves * kGroupRows * 8);
+        IvrProf prof("select_final", s, (double)waves * kGroupRows * 8, true);
         hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(sel_threads((int64_t)ksel * kGroupRows)), 0, s, sk, 0, k,
                            id_base, (uint32_t *)nullptr, D + (int64_t)q0 * k, I + (int64_t)q0 * k, (const int64_t *)nullptr, skip);
         IVR_LAUNCH_CHECK();
@@ -1094,7 +1095,7 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         const int ksel2 = kp + 1;
         SrcGroupMax sg{x->gmax, mstride, ngroups};
         {
-            IvrProf prof("select_groups", s, (double)nqc * ngroups * 4);
+            IvrProf prof("select_groups", s, (double)nqc * ngroups * 4, true);
             hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(sel_threads(ngroups)), 0, s, sg, 0, ksel2,
                                (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr, (const int *)nullptr,
                                VerifyArgs(), tile_flag);
@@ -1102,14 +1103,14 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         IVR_LAUNCH_CHECK();
         const int64_t waves = (int64_t)nqc * kp;
         {
-            IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4);
+            IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4, true);
             hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)waves), dim3(256), 0, s, x->data, qtile, x->dp4,
                                x->ntotal, x->sel, ksel2, kp, nqc, x->cand, (const int *)nullptr);
         }
         IVR_LAUNCH_CHECK();
         {
             SrcKeys sk{x->cand, (int64_t)kp * kGroupRows};
-            IvrProf prof("select_final", s, (double)waves * kGroupRows * 8);
+            IvrProf prof("select_final", s, (double)waves * kGroupRows * 8, true);
             VerifyArgs vf;
             vf.gmax = x->gmax;
             vf.mstride = mstride;

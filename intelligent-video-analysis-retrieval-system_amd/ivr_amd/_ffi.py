@@ -148,7 +148,8 @@ def f3(v):
 
 
 def profile_enable(on=True, device=0):
-    check(load().ivr_profile_enable(context(device), int(bool(on))))
+    """on: False / True (level 1: the kernels that carry a step) / 2 (also the short search-tail and append launches)."""
+    check(load().ivr_profile_enable(context(device), int(on)))
 
 
 def profile_reset(device=0):

@@ -13,7 +13,7 @@ for nq in (48, 100, 256, 1000):
     for _ in range(2):
         idx.search_device(q, 10, normalize=True)
     torch.cuda.synchronize()
-    _ffi.profile_reset(); _ffi.profile_enable(True)
+    _ffi.profile_reset(); _ffi.profile_enable(2)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):

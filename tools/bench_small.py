@@ -32,7 +32,7 @@ for nq in (1, 10, 16, 32, 64):
     for _ in range(3):
         idx.search_device(q, 10, normalize=True)
     torch.cuda.synchronize()
-    _ffi.profile_reset(); _ffi.profile_enable(True)
+    _ffi.profile_reset(); _ffi.profile_enable(2)
     for _ in range(10):
         idx.search_device(q, 10, normalize=True)
     torch.cuda.synchronize(); _ffi.profile_enable(False)
