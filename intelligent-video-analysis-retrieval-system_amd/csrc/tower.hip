@@ -204,6 +204,14 @@ int layer_gemm(ivr_tower *t, bool site_fp8, int epi, GemmArgs &g, const std::str
     return ivr_launch_gemm(t->d.compute == IVR_COMPUTE_F32, epi, g, s);
 }
 
+int env_zigzag() {
+    static const int v = [] {
+        const char *e = getenv("IVR_ZIGZAG");
+        return e ? (atoi(e) != 0) : 1;
+    }();
+    return v;
+}
+
 // one transformer stack over `rows` = n*T residual rows already in t->resid
 int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
     const ivr_tower_desc &d = t->d;
@@ -213,29 +221,41 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
     // dtype of each site's A operand (LN output / attention output / MLP hidden): e4m3 where the consuming site is
     auto kind = [&](bool site8) { return f32 ? OUT_F32 : site8 ? OUT_FP8 : OUT_BF16; };
     const int D = d.width, rows = n * T;
+    // Producer / consumer order.  Every kernel of a block streams a few hundred MB that the next one reads back; the Infinity
+    // Cache (256 MiB) still holds what a kernel wrote LAST.  So consecutive kernels walk the rows in opposite directions: the
+    // consumer starts where its producer just finished and takes that part from the cache instead of HBM (IVR_ZIGZAG=0: all
+    // ascending, as before).  fc2 ascending -> LN1 descending -> qkv / attention ascending -> attn-out descending -> LN2
+    // ascending -> fc1 descending -> fc2 ascending.
+    const int zz = env_zigzag();
     int rc;
     for (int i = 0; i < d.layers; ++i) {
         const std::string p = "l" + std::to_string(i) + ".";
         if (t->debug_out && t->debug_layer == i)
             IVR_HIP(hipMemcpyAsync(t->debug_out, t->resid, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s));
         rc = ivr_launch_layernorm(kind(q8), t->resid, 1, nullptr, wptr<float>(t, p + "ln1_g"), wptr<float>(t, p + "ln1_b"), d.ln_eps,
-                                  t->xn, rows, D, s);
+                                  t->xn, rows, D, s, zz);
         if (rc) return rc;
         GemmArgs g;
-        g.A = t->xn;
-        g.lda = D;
-        g.ldw = D;
-        g.M = rows;
-        g.N = 3 * D;
-        g.K = D;
-        g.bias = wptr<float>(t, p + "qkv_b");
-        g.out = t->qkv;                  // bf16 in the fp8 mode too: the attention products stay on the bf16 MFMA
-        g.ldo = 3 * D;
-        g.tag = "gemm_qkv";
-        rc = layer_gemm(t, q8, EPI_STORE, g, p + "qkv_w", s);
-        if (rc) return rc;
-        rc = ivr_launch_attention(f32, t->qkv, t->att, n, T, D, d.heads, d.causal, s, o8);
-        if (rc) return rc;
+        if (!f32 && !q8 && ivr_fused_qkv_attention_ok(rows, T, D, d.heads, d.causal)) {
+            // short sequences, bf16: projection and attention in one kernel, the QKV activations stay in LDS
+            rc = ivr_launch_qkv_attention(t->xn, wptr<void>(t, p + "qkv_w"), wptr<float>(t, p + "qkv_b"), t->att, n, T, D, d.heads, o8, s);
+            if (rc) return rc;
+        } else {
+            g.A = t->xn;
+            g.lda = D;
+            g.ldw = D;
+            g.M = rows;
+            g.N = 3 * D;
+            g.K = D;
+            g.bias = wptr<float>(t, p + "qkv_b");
+            g.out = t->qkv;                  // bf16 in the fp8 mode too: the attention products stay on the bf16 MFMA
+            g.ldo = 3 * D;
+            g.tag = "gemm_qkv";
+            rc = layer_gemm(t, q8, EPI_STORE, g, p + "qkv_w", s);                  // ascending, and so is the attention kernel
+            if (rc) return rc;
+            rc = ivr_launch_attention(f32, t->qkv, t->att, n, T, D, d.heads, d.causal, s, o8);
+            if (rc) return rc;
+        }
         g = GemmArgs();
         g.A = t->att;
         g.lda = D;
@@ -247,6 +267,7 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.resid = t->resid;
         g.ldr = D;
         g.tag = "gemm_attn_out";
+        g.reverse_m = zz;
         rc = layer_gemm(t, o8, EPI_RESID, g, p + "o_w", s);
         if (rc) return rc;
         rc = ivr_launch_layernorm(kind(f18), t->resid, 1, nullptr, wptr<float>(t, p + "ln2_g"), wptr<float>(t, p + "ln2_b"), d.ln_eps,
@@ -269,6 +290,7 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.ldo = d.mlp;
         g.act = d.act;
         g.out8 = f18 && f28;             // the e4m3 GEMM writes fc2's e4m3 operand itself
+        g.reverse_m = zz;
         g.tag = "gemm_fc1";
         rc = layer_gemm(t, f18, EPI_STORE, g, p + "fc1_w", s);
         if (rc) return rc;
@@ -599,6 +621,15 @@ int ivr_quantize_e4m3_host(const float *src, uint8_t *dst, int64_t n) {
     for (int64_t i = 0; i < n; ++i) dst[i] = host_e4m3(src[i]);
     return IVR_OK;
 }
+
+#ifdef IVR_GEMM_STAMPS
+// diagnostic build only: launch the fused QKV + attention kernel of layer 0 once more on the workspace of the last call
+int ivr_debug_last_qkv_attention(ivr_tower *t, int n, ivr_stream stream) {
+    const ivr_tower_desc &d = t->d;
+    return ivr_launch_qkv_attention(t->xn, wptr<void>(t, "l0.qkv_w"), wptr<float>(t, "l0.qkv_b"), t->att, n, d.tokens, d.width, d.heads, false,
+                                    (hipStream_t)stream);
+}
+#endif
 
 int ivr_tower_debug_hidden(ivr_tower *t, int layer, int n, float *out, ivr_stream) {
     IVR_REQUIRE(t && out, "ivr_tower_debug_hidden: NULL argument");

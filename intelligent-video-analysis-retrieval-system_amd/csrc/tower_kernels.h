@@ -23,6 +23,7 @@ struct GemmArgs {
     const float *colscale = nullptr;   // fp8 GEMM: per-output-column dequantisation scale [N] (NULL = 1)
     int out8 = 0;                  // fp8 GEMM, EPI_STORE: write saturated e4m3 instead of bf16
     int wide_epi = 0;              // set by the launcher: 256 x 256 kernel may use the row-wide LDS-staged epilogue
+    int reverse_m = 0;             // walk the row panels from the last to the first (see run_layers: producer / consumer order)
     int skip_mod = 0;              // EPI_RESID: rows r with r % skip_mod == 0 are left untouched (0 = none); the fp8 mode's
                                    // token-0 rows are updated by a bf16 side GEMM instead
 };
@@ -31,9 +32,13 @@ int ivr_launch_gemm(bool f32, int epi, const GemmArgs &g, hipStream_t s);
 int ivr_launch_gemm_fp8(int epi, const GemmArgs &g, hipStream_t s);   // A, W: e4m3 bytes; 256 x 256 kernel only
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_FP8 = 2 };
 int ivr_launch_layernorm(int out_kind, const float *x, int row_mul, const int *offs, const float *g, const float *b, float eps,
-                         void *out, int rows, int D, hipStream_t s);
+                         void *out, int rows, int D, hipStream_t s, int reverse = 0);
 int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int D, int heads, int causal, hipStream_t s,
                          bool out_fp8 = false);
+// fused QKV projection + attention (bf16, T <= 64, not causal): xn [n*T, D] bf16, w [3D, D] bf16, bias [3D] -> att [n*T, D]
+bool ivr_fused_qkv_attention_ok(int M, int T, int D, int heads, int causal);
+int ivr_launch_qkv_attention(const void *xn, const void *w, const float *bias, void *att, int n, int T, int D, int heads, bool out_fp8,
+                             hipStream_t s, int reverse = 0);
 int ivr_launch_vision_cls(float *resid, const float *cls, const float *pos, int n, int T, int D, hipStream_t s);
 int ivr_launch_text_embed(float *resid, const int64_t *ids, const float *tok, const float *pos, int q, int T, int D, int vocab,
                           int eos, int *eos_pos, hipStream_t s);

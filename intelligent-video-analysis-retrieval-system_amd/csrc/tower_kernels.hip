@@ -143,10 +143,11 @@ __global__ void eos_pos_kernel(const int64_t *__restrict__ ids, int q, int T, in
 template <typename TOut>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int row_mul, const int *__restrict__ offs,
                                                         const float *__restrict__ g, const float *__restrict__ b, float eps,
-                                                        TOut *__restrict__ out, int rows, int D) {
+                                                        TOut *__restrict__ out, int rows, int D, int reverse) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (reverse) row = rows - 1 - row;
     const int64_t srow = (int64_t)row * row_mul + (offs ? offs[row] : 0);
     const float4 *src = reinterpret_cast<const float4 *>(x + srow * D);
     const int nv = D >> 2;
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         const int gme = min(gm, lx - grp * gm);
         tm = xcd + 8 * (grp * gm + within % gme);
         tn = within / gme;
+        if (g.reverse_m) tm = MT - 1 - tm;
     }
     const int m0 = tm * BM, n0 = tn * BN;
     constexpr int EPR = ROWB / (int)sizeof(T);   // elements of K per step
@@ -526,7 +528,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4]
 
 #ifdef IVR_GEMM_STAMPS
 // diagnostic build only: per-workgroup s_memtime stamps (entry, first stage landed, K loop done, stores drained)
-__device__ unsigned long long ivr_gemm_stamps[16384][6];   // [4], [5]: s_memrealtime (100 MHz) at stamps 0 and 3
+__device__ unsigned long long ivr_gemm_stamps[16384][8];   // [4], [5]: s_memrealtime (100 MHz) at stamps 0 and 3; [6]: extra stamp
 #define IVR_STAMP(I)                                                                                       \
     if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                          \
         ivr_gemm_stamps[blockIdx.x][I] = __builtin_amdgcn_s_memtime();                                     \
@@ -579,6 +581,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
         const int gme = min(gm, lx - grp * gm);
         tm = xcd + 8 * (grp * gm + within % gme);
         tn = within / gme;
+        if (g.reverse_m) tm = MT - 1 - tm;
     }
     const int m0 = tm * LBM, n0 = tn * LBN;
     constexpr int EPR = ROWB / (int)sizeof(T);
@@ -833,6 +836,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big8_kernel(GemmArgs g) {
         const int gme = min(gm, lx - grp * gm);
         tm = xcd + 8 * (grp * gm + within % gme);
         tn = within / gme;
+        if (g.reverse_m) tm = MT - 1 - tm;
     }
     const int m0 = tm * LBM, n0 = tn * LBN;
     const int KT = g.K / ROWB;                           // 128 e4m3 elements per stage
@@ -1572,6 +1576,328 @@ __global__ __launch_bounds__(256, 5) void attention_mfma_short_kernel(const unsi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused QKV projection + attention for short sequences (T <= 64: CLIP ViT-B/32 has T = 50), bf16.
+// Replaces gemm_big_kernel<bf16, EPI_STORE> (qkv) + attention_mfma_short_kernel: the [rows, 3D] QKV activations never go to
+// HBM (4608 B written + 4608 B read per token row and layer at D = 768; the attention kernel was a pure HBM round trip).
+//   * one workgroup = (G whole images, one head): an M tile of G*T rows (G = 256 / T: 250 rows at T = 50) times the 192 output
+//     columns q_h | k_h | v_h of head h.  The K loop is gemm_big_kernel's (three X slots, two W slots, LDS-DMA, fragment sets
+//     software-pipelined across the mid-stage barrier) with three column tiles per wave instead of four;
+//   * after the K loop the accumulators (+ bias) go to LDS as bf16 - the same rounding the QKV buffer had - in the layouts the
+//     attention products read without bank conflicts: Q and K rows with the GEMM's chunk ^ (row & 7) swizzle (ds_read_b128
+//     fragments), V rows with the 32-byte segment swizzle of the transposing ds_read_b64_tr_b16;
+//   * the (image, 16-query tile) units of the tile are dealt to the eight waves; each unit is the arithmetic of
+//     attention_mfma_short_kernel, operation for operation (S^T = K Q^T, base-2 softmax, P packed to bf16, O^T = V^T P^T), so
+//     the result is bit-identical to the unfused path; only att[rows, 64] is written.
+// Tile order as in the GEMMs: the 12 head workgroups of a row panel run on one XCD and share the panel through its L2.
+// ---------------------------------------------------------------------------------------------
+struct QkvAttnArgs {
+    const void *X = nullptr;      // LayerNorm output [rows, D] bf16
+    const void *W = nullptr;      // fused QKV weight [3D, D] bf16 (rows: q | k | v, attention scale folded into q)
+    const float *bias = nullptr;  // [3D]
+    void *att = nullptr;          // [rows, D] bf16 (or e4m3 bytes when out8)
+    int M = 0, D = 0, T = 0, heads = 0, G = 0, group_m = 4, reverse = 0;
+};
+
+constexpr int QA_WBYTES = 192 * ROWB;                         // one W stage: q_h, k_h, v_h rows = 24 KiB
+constexpr int QA_LDS = 3 * LX_BYTES + 2 * QA_WBYTES;          // 144 KiB
+constexpr int QA_REGION = 264 * ROWB;                         // Q / K / V image after the K loop: 256 rows + 8 zeroed pad rows
+
+template <typename TOut>
+__global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs g) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef unsigned short T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    IVR_STAMP(0)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int RT = g.G * g.T;                                  // rows per tile
+    const int MT = (g.M + RT - 1) / RT, NT = g.heads;
+    int tm, h;
+    {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;
+        if (i >= lx * NT) return;
+        const int gm = g.group_m;
+        const int per = gm * NT, grp = i / per, within = i - grp * per;
+        const int gme = min(gm, lx - grp * gm);
+        tm = xcd + 8 * (grp * gm + within % gme);
+        h = within / gme;
+        if (g.reverse) tm = MT - 1 - tm;
+    }
+    const int m0 = tm * RT;
+    const int KT = g.D / 64;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // DMA pieces of 1 KiB (8 rows x 128 B): 32 of X, 24 of W per stage; wave w issues X pieces 4w..4w+3 and W pieces 3w..3w+2.
+    // W piece p covers rows 8p..8p+7 of the 192-row head tile: third p >> 3 (q, k, v), rows h*64 + 8*(p & 7) of that third.
+    unsigned voffX[4], voffW;
+    {
+        const int c = (lane & 7) ^ (lane >> 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) voffX[j] = (unsigned)((8 * (wave * 4 + j) + (lane >> 3)) * g.D) * 2u + c * 16;
+        voffW = (unsigned)((lane >> 3) * g.D) * 2u + c * 16;
+    }
+    unsigned swW[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int p = wave * 3 + j;
+        swW[j] = (unsigned)(((p >> 3) * g.D + h * 64 + 8 * (p & 7)) * g.D) * 2u;
+    }
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.X), 0, (int)((int64_t)g.M * g.D * 2), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)3 * g.D * g.D * 2), 0x00020000);
+    const unsigned sx0 = (unsigned)m0 * (unsigned)g.D * 2u;
+    constexpr int WBASE = 3 * LX_BYTES;
+    auto piece = [&](int kt, int xs, int j) {          // j < 4: X piece (slot xs); 4..6: W piece (slot kt & 1)
+        const unsigned adv = (unsigned)kt * ROWB;
+        if (j < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(smem + xs * LX_BYTES + (wave * 4 + j) * 1024),
+                                                     16, voffX[j], sx0 + adv, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsW, (__attribute__((address_space(3))) void *)(smem + WBASE + (kt & 1) * QA_WBYTES + (wave * 3 + j - 4) * 1024), 16, voffW,
+                swW[j - 4] + adv, 0, 0);
+    };
+    unsigned foX[2], foW[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const unsigned f = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+        foX[kk] = lds0 + (wm * 128) * ROWB + f;
+        foW[kk] = lds0 + WBASE + (wn * 48) * ROWB + f;
+    }
+
+    f32x4 acc[3][8];   // [nt][mt]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the bias of the wave's three column tiles, fetched now so that its latency is long gone when the epilogue needs it
+    float4 bq[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int col = wn * 48 + nt * 16 + 4 * (lane >> 4);
+        bq[nt] = *reinterpret_cast<const float4 *>(g.bias + (col >> 6) * g.D + h * 64 + (col & 63));
+    }
+
+#define QA_ROW(XF, WF, MTI)                                                                                \
+    _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) mma_chunk<T>(WF[nt], XF[MTI], acc[nt][MTI]);          \
+    __builtin_amdgcn_sched_barrier(0);
+#define QA_RD4(DST, ADDR, O0)                                                                              \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[0]) : "v"(ADDR), "n"(O0));                      \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[1]) : "v"(ADDR), "n"(O0 + 2048));               \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[2]) : "v"(ADDR), "n"(O0 + 4096));               \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[3]) : "v"(ADDR), "n"(O0 + 6144));
+#define QA_RD3(DST, ADDR)                                                                                  \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(DST[0]) : "v"(ADDR));                                         \
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(DST[1]) : "v"(ADDR));                             \
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(DST[2]) : "v"(ADDR));
+#define QA_LGKM(N)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 xa0[8], wa0[3], xa1[8], wa1[3];
+    u32x4 *x0lo = xa0, *x0hi = xa0 + 4, *x1lo = xa1, *x1hi = xa1 + 4;
+    // prologue (KT >= 3 is checked by the launcher): stage 0, stage 1, X(2), in the order the counted waits rely on
+#pragma unroll
+    for (int j = 0; j < 7; ++j) piece(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) piece(1, 1, j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) piece(2, 2, j);
+    asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory");
+    IVR_STAMP(1)
+    QA_RD3(wa0, foW[0])
+    QA_RD4(x0lo, foX[0], 0)
+    QA_RD4(x0hi, foX[0], 8192)
+    int xs = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int xs1 = xs == 2 ? 0 : xs + 1;
+        const unsigned xoff = xs * LX_BYTES, woff = (kt & 1) * QA_WBYTES, nxoff = xs1 * LX_BYTES, nwoff = ((kt + 1) & 1) * QA_WBYTES;
+        const bool tail = kt >= 1 && kt + 2 < KT;
+        const bool morew = kt + 2 < KT, morex = kt + 3 < KT, next = kt + 1 < KT;
+        const unsigned wa = foW[1] + woff, xa = foX[1] + xoff, nwa = foW[0] + nwoff, nxa = foX[0] + nxoff;
+        QA_LGKM(4)                      // W + first four X fragments of set 0
+        QA_ROW(xa0, wa0, 0)
+        if (tail) piece(kt + 2, xs1 == 2 ? 0 : xs1 + 1, 2);
+        QA_ROW(xa0, wa0, 1)
+        QA_RD3(wa1, wa)
+        QA_ROW(xa0, wa0, 2)
+        if (tail) piece(kt + 2, xs1 == 2 ? 0 : xs1 + 1, 3);
+        QA_ROW(xa0, wa0, 3)
+        QA_RD4(x1lo, xa, 0)
+        QA_LGKM(7)                      // all of set 0
+        QA_ROW(xa0, wa0, 4)
+        QA_ROW(xa0, wa0, 5)
+        QA_RD4(x1hi, xa, 8192)
+        QA_ROW(xa0, wa0, 6)
+        QA_ROW(xa0, wa0, 7)
+        QA_LGKM(0)
+        if (next) {
+            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        QA_ROW(xa1, wa1, 0)
+        if (morew) piece(kt + 2, 0, 4);
+        QA_ROW(xa1, wa1, 1)
+        if (next) { QA_RD3(wa0, nwa) }
+        if (morew) piece(kt + 2, 0, 5);
+        QA_ROW(xa1, wa1, 2)
+        if (morew) piece(kt + 2, 0, 6);
+        QA_ROW(xa1, wa1, 3)
+        if (next) { QA_RD4(x0lo, nxa, 0) }
+        QA_ROW(xa1, wa1, 4)
+        if (morex) piece(kt + 3, xs, 0);
+        QA_ROW(xa1, wa1, 5)
+        if (next) { QA_RD4(x0hi, nxa, 8192) }
+        QA_ROW(xa1, wa1, 6)
+        if (morex) piece(kt + 3, xs, 1);
+        QA_ROW(xa1, wa1, 7)
+        xs = xs1;
+    }
+    QA_LGKM(0)
+#undef QA_ROW
+#undef QA_RD4
+#undef QA_RD3
+#undef QA_LGKM
+    IVR_STAMP(2)
+    __builtin_amdgcn_s_barrier();                             // every wave has read its last fragments: the LDS is free
+
+    // ---- accumulators + bias -> bf16 Q | K | V images in LDS
+    unsigned char *const qreg = smem, *const kreg = smem + QA_REGION, *const vreg = smem + 2 * QA_REGION;
+    {
+        const int r = lane & 15, gq = lane >> 4;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int col = wn * 48 + nt * 16 + 4 * gq;       // 0..191: region col >> 6, head dim col & 63
+            const int reg3 = col >> 6, dh = col & 63, ch = dh >> 3;
+            const float4 bv = bq[nt];
+            unsigned char *base = smem + reg3 * QA_REGION + (dh & 7) * 2;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int m = wm * 128 + mt * 16 + r;
+                const f32x4 a = acc[nt][mt];
+                uint2 o;
+                o.x = ivr_pack_bf16x2(a[0] + bv.x, a[1] + bv.y);
+                o.y = ivr_pack_bf16x2(a[2] + bv.z, a[3] + bv.w);
+                const unsigned pos = reg3 == 2 ? (unsigned)((((ch >> 1) ^ ((m >> 1) & 3)) << 5) | ((ch & 1) << 4))
+                                               : (unsigned)((ch ^ (m & 7)) << 4);
+                *reinterpret_cast<uint2 *>(base + m * ROWB + pos) = o;
+            }
+        }
+        // rows 256..263 behind the K and V images: key blocks of the tile's last image may reach them (masked scores, P = 0)
+        if (tid < 128) *reinterpret_cast<uint4 *>((tid < 64 ? kreg : vreg) + 256 * ROWB + (tid & 63) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+#ifdef IVR_GEMM_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 16384) ivr_gemm_stamps[blockIdx.x][6] = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- attention: units (image, 16-query tile) dealt round-robin to the waves
+    const int Tn = g.T, nqt = (Tn + 15) >> 4, units = g.G * nqt;
+    const int gl = lane >> 4, c = lane & 15;
+    constexpr float L2E = 1.4426950408889634f;
+    for (int u = wave; u < units; u += 8) {
+        const int img = u / nqt, qt = u - img * nqt;
+        const int R0 = img * Tn;                                // first tile row of the image
+        if (m0 + R0 >= g.M) continue;                           // image past the end of the batch (last panel)
+        const int q = qt * 16 + c;
+        // All LDS reads of the unit go out together - Q fragments (B operand of S^T: row R0 + q, chunks 4 ks + gl), K fragments
+        // (A operand: rows R0 + 16 kt + c) and the sixteen transposed V^T pieces, which do not depend on the softmax - and are
+        // waited for once: issued one dependent group at a time the unit was a chain of ten LDS round trips.
+        uint4 qf[2], kf[2][4];
+        uint2 vt[4][4];                                         // [dh tile nt][16-key block]
+        {
+            const int rq = R0 + q;
+            const unsigned qa = (unsigned)(size_t)qreg + rq * ROWB, qx = rq & 7;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) asm volatile("ds_read_b128 %0, %1" : "=v"(qf[ks]) : "v"(qa + (((4 * ks + gl) ^ qx) << 4)));
+            // the four key tiles are 16 rows = 2048 bytes apart and share (row & 7)
+            const int rk = R0 + c;
+            const unsigned ka = (unsigned)(size_t)kreg + rk * ROWB, kx = rk & 7;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned a0 = ka + (((4 * ks + gl) ^ kx) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(kf[ks][0]) : "v"(a0));
+                asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(kf[ks][1]) : "v"(a0));
+                asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(kf[ks][2]) : "v"(a0));
+                asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(kf[ks][3]) : "v"(a0));
+            }
+            // V^T: this lane addresses key row 4 gl + (c >> 2) of a 16-key block, 8 bytes (c & 3) of the 32-byte segment nt
+            const int vrow = R0 + 4 * gl + (c >> 2);
+            const unsigned vbase = (unsigned)(size_t)vreg + (unsigned)vrow * ROWB + (c & 3) * 8;
+            const int xr = (vrow >> 1) & 3;                      // key blocks start 16 rows apart: (row >> 1) & 3 is the same in all four
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const unsigned va = vbase + ((nt ^ xr) << 5);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[nt][0]) : "v"(va));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(vt[nt][1]) : "v"(va));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(vt[nt][2]) : "v"(va));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(vt[nt][3]) : "v"(va));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[0][kt]), __builtin_bit_cast(bf16x8_t, qf[0]), a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[1][kt]), __builtin_bit_cast(bf16x8_t, qf[1]), a, 0, 0, 0);
+            if (kt * 16 + 15 >= Tn) {             // wave-uniform: only a tile that reaches past the sequence needs the mask
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + gl * 4 + r >= Tn) a[r] = -INFINITY;
+            }
+            mx = vmax3(mx, a[0], a[1]);
+            mx = vmax3(mx, a[2], a[3]);
+            sc[kt] = a;
+        }
+        mx = quad_max(mx);                    // finite: key 0 is visible to every query
+        const float mb = -mx * L2E;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], L2E, mb));      // masked (-inf) -> 0
+                sc[kt][r] = pv;
+                sum += pv;
+            }
+        sum = quad_sum(sum);
+        uint4 pf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            pf[ks].x = ivr_pack_bf16x2(sc[2 * ks][0], sc[2 * ks][1]);
+            pf[ks].y = ivr_pack_bf16x2(sc[2 * ks][2], sc[2 * ks][3]);
+            pf[ks].z = ivr_pack_bf16x2(sc[2 * ks + 1][0], sc[2 * ks + 1][1]);
+            pf[ks].w = ivr_pack_bf16x2(sc[2 * ks + 1][2], sc[2 * ks + 1][3]);
+        }
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        const int64_t grow = (int64_t)m0 + R0 + q;
+        TOut *op = reinterpret_cast<TOut *>(g.att) + grow * g.D + h * 64 + gl * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 vf = make_uint4(vt[nt][2 * ks].x, vt[nt][2 * ks].y, vt[nt][2 * ks + 1].x, vt[nt][2 * ks + 1].y);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[ks]), o, 0, 0, 0);
+            }
+            if (q < Tn && grow < g.M) {
+                const float v[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+                El<TOut>::store4(op + nt * 16, v);
+            }
+        }
+    }
+#ifdef IVR_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                            // the slowest wave of the workgroup
+    IVR_STAMP(3)
+#endif
+}
+
 template <typename T, int EPI, int ACT>
 int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
@@ -1672,20 +1998,66 @@ int ivr_launch_gemm_fp8(int epi, const GemmArgs &g, hipStream_t s) {
     return launch_gemm8_t<EPI_STORE, -1, false>(g, s);
 }
 
+bool ivr_fused_qkv_attention_ok(int M, int T, int D, int heads, int causal) {
+    // whole images per 256-row tile, at least three K stages, one 64-wide head per column block; large problems only by default
+    // (IVR_FUSED_QKV=1 forces it wherever it is valid, 0 switches it off)
+    if (T < 1 || T > 64 || causal || D % 64 != 0 || D < 192 || heads * 64 != D || M % T != 0) return false;
+    if ((int64_t)M * D * 2 >= 0x7fffffff || (int64_t)3 * D * D * 2 >= 0x7fffffff) return false;
+    const int mode = env_int("IVR_FUSED_QKV", -1);
+    if (mode == 0) return false;
+    if (mode == 1) return true;
+    const int RT = (256 / T) * T;
+    return (int64_t)((M + RT - 1) / RT) * heads >= 256;       // fills the chip (one workgroup per CU)
+}
+
+int ivr_launch_qkv_attention(const void *xn, const void *w, const float *bias, void *att, int n, int T, int D, int heads, bool out_fp8,
+                             hipStream_t s, int reverse) {
+    if (n <= 0) return IVR_OK;
+    const int M = n * T;
+    IVR_REQUIRE(ivr_fused_qkv_attention_ok(M, T, D, heads, 0) || env_int("IVR_FUSED_QKV", -1) == 1, "fused qkv+attention: unsupported shape");
+    const auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    IVR_REQUIRE(al16(xn) && al16(w) && al16(bias) && al16(att), "fused qkv+attention: operands must be 16-byte aligned");
+    QkvAttnArgs g;
+    g.X = xn;
+    g.W = w;
+    g.bias = bias;
+    g.att = att;
+    g.M = M;
+    g.D = D;
+    g.T = T;
+    g.heads = heads;
+    g.G = 256 / T;
+    g.group_m = std::max(1, env_int("IVR_GEMM_GROUP_M", 4));
+    g.reverse = reverse;
+    const int RT = g.G * T, MT = (M + RT - 1) / RT;
+    const int grid = 8 * ((MT + 7) / 8) * heads;
+    // FLOP: the projection (2 M 3D D) and the attention products (4 T^2 64 per image and head)
+    IvrProf prof("gemm_qkv_attention", s, 2.0 * M * 3.0 * D * D + 4.0 * n * heads * (double)T * T * 64);
+    if (out_fp8) {
+        if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(qkv_attn_kernel<unsigned char>), QA_LDS)) return rc;
+        hipLaunchKernelGGL(qkv_attn_kernel<unsigned char>, dim3(grid), dim3(512), QA_LDS, s, g);
+    } else {
+        if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(qkv_attn_kernel<unsigned short>), QA_LDS)) return rc;
+        hipLaunchKernelGGL(qkv_attn_kernel<unsigned short>, dim3(grid), dim3(512), QA_LDS, s, g);
+    }
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
 int ivr_launch_layernorm(int out_kind, const float *x, int row_mul, const int *offs, const float *g, const float *b, float eps,
-                         void *out, int rows, int D, hipStream_t s) {
+                         void *out, int rows, int D, hipStream_t s, int reverse) {
     if (rows <= 0) return IVR_OK;
     IVR_REQUIRE(D % 4 == 0 && D <= 2048, "layernorm: D=%d", D);
     const unsigned grid = (unsigned)ivr_ceil_div(rows, 4);
     IvrProf prof("layernorm", s, (double)rows * D * (4 + (out_kind == OUT_F32 ? 4 : out_kind == OUT_FP8 ? 1 : 2)));
     if (out_kind == OUT_F32)
-        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, x, row_mul, offs, g, b, eps, (float *)out, rows, D);
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, x, row_mul, offs, g, b, eps, (float *)out, rows, D, reverse);
     else if (out_kind == OUT_FP8)
         hipLaunchKernelGGL(layernorm_kernel<unsigned char>, dim3(grid), dim3(256), 0, s, x, row_mul, offs, g, b, eps,
-                           (unsigned char *)out, rows, D);
+                           (unsigned char *)out, rows, D, reverse);
     else
         hipLaunchKernelGGL(layernorm_kernel<unsigned short>, dim3(grid), dim3(256), 0, s, x, row_mul, offs, g, b, eps,
-                           (unsigned short *)out, rows, D);
+                           (unsigned short *)out, rows, D, reverse);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
@@ -1835,6 +2207,6 @@ int ivr_launch_f_normalize(const float *x, float *out, int n, int d, int normali
 
 #ifdef IVR_GEMM_STAMPS
 extern "C" int ivr_debug_gemm_stamps(unsigned long long *host_out, int nblocks) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ivr_gemm_stamps), sizeof(unsigned long long) * 6 * nblocks) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ivr_gemm_stamps), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? 0 : -2;
 }
 #endif

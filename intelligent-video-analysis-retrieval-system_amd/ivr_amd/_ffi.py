@@ -10,7 +10,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libivr_hip.so")
+# IVR_LIB: diagnostics only (e.g. a -DIVR_GEMM_STAMPS build for tools/gemm_stamps.py)
+LIB_PATH = os.environ.get("IVR_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libivr_hip.so")
 
 IVR_MAX_K = 2048
 # flags of ivr_preprocess

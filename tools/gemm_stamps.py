@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: where a 256x256 GEMM workgroup spends its cycles (needs a library built with -DIVR_GEMM_STAMPS)."""
+"""Diagnostic: where a 256x256 GEMM workgroup (and the fused QKV + attention workgroup) spends its cycles.  Needs a library built
+with -DIVR_GEMM_STAMPS:  make -C .../csrc stamps  ->  lib/libivr_hip_stamps.so, then  IVR_LIB=.../libivr_hip_stamps.so python tools/gemm_stamps.py"""
 import ctypes as C
 import os
 import sys
@@ -26,7 +27,7 @@ for name, m, n, k, epi, act in shapes:
         linear(x, w, b, act=act, epilogue=epi, resid=r)
     torch.cuda.synchronize()
     nb = min(16384, ((m + 255) // 256) * ((n + 255) // 256))
-    st = np.zeros((nb, 6), dtype=np.uint64)
+    st = np.zeros((nb, 8), dtype=np.uint64)
     assert lib.ivr_debug_gemm_stamps(st.ctypes.data_as(C.c_void_p), nb) == 0
     st = st.astype(np.int64)
     pro, loop, epi_c = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
@@ -42,3 +43,28 @@ for name, m, n, k, epi, act in shapes:
     clk = span / real / 1e9
     print(f"{name:9s} KT={kt:3d} blocks={nb:6d}  prologue {np.median(pro):8.0f}  loop {np.median(loop):8.0f} ({np.median(loop) / kt:6.0f}/stage, ideal 2048)"
           f"  epilogue {np.median(epi_c):8.0f}  total/block {np.median(st[:, 3] - st[:, 0]):8.0f}  span {span} cyc = {real * 1e3:.3f} ms -> in-kernel clock {clk:.2f} GHz")
+
+# fused QKV projection + attention (ViT-B/32 shape: T = 50, D = 768, 12 heads): one tower layer through the debug entry point
+from ivr_amd import config as Cfg  # noqa: E402
+from ivr_amd.tower import Tower  # noqa: E402
+from ivr_amd.weights import make_weights  # noqa: E402
+
+os.environ["IVR_FUSED_QKV"] = "1"
+cfg = Cfg.TowerConfig("stamps-b32-1layer", "vision", 768, 1, 12, 3072, 50, 512, image=224, patch=32)
+tw = Tower(cfg, make_weights(cfg, 1), max_batch=B)
+px = (torch.randn((B * 49, 3072), device="cuda") * 0.5).to(torch.bfloat16)
+for _ in range(3):
+    tw.encode_patches(px, B)
+torch.cuda.synchronize()
+# the last launches of a layer overwrite the stamps: run the fused kernel last by reading right after a dedicated call
+lib.ivr_debug_last_qkv_attention.restype = C.c_int
+nb = min(16384, 8 * (((B * 50 + 249) // 250 + 7) // 8) * 12)
+st = np.zeros((nb, 8), dtype=np.uint64)
+assert lib.ivr_debug_last_qkv_attention(tw._h, B, None) == 0
+torch.cuda.synchronize()
+assert lib.ivr_debug_gemm_stamps(st.ctypes.data_as(C.c_void_p), nb) == 0
+st = st.astype(np.int64)
+st = st[st[:, 0] > 0]
+print(f"qkv_attn  blocks={len(st)}  prologue {np.median(st[:, 1] - st[:, 0]):8.0f}  K loop {np.median(st[:, 2] - st[:, 1]):8.0f} "
+      f"({np.median(st[:, 2] - st[:, 1]) / 12:6.0f}/stage, 1536 = MFMA-bound)  acc->LDS {np.median(st[:, 6] - st[:, 2]):8.0f}  "
+      f"attention {np.median(st[:, 3] - st[:, 6]):8.0f}  total/block {np.median(st[:, 3] - st[:, 0]):8.0f}")
