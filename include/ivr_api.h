@@ -222,10 +222,26 @@ int ivr_topk_merge(ivr_ctx *ctx, const float *D_parts /*DEV*/, const int64_t *I_
 int ivr_dedup_keep_mask(ivr_ctx *ctx, const float *emb /*DEV*/, int n, int d, float threshold,
                         float *state /*DEV*/, uint8_t *keep /*DEV*/, ivr_stream stream);
 
+/* In-scene similarity filter of the keyframe pipeline, filter_similar_frames_in_scene at filter.py:178-222, as ONE launch per
+ * scene: emb DEV float32 [n,d] = the scene's frames in order; keep[0] = 1; keep[i] = 1 iff i is at least min_distance after the
+ * last kept frame and cos(emb[i], emb[last kept]) < threshold (the caller appends the scene's last frame, filter.py:218-220). */
+int ivr_scene_keep_mask(ivr_ctx *ctx, const float *emb /*DEV*/, int n, int d, float threshold, int min_distance,
+                        uint8_t *keep /*DEV*/, ivr_stream stream);
+
 /* cos(a[i], b[i]) for i < n (DEV float32 [n,d] each), sklearn cosine_similarity conventions.  Replaces the per-pair
  * cosine_similarity([x],[y])[0][0] calls of the keyframe filter (filter.py:147, filter.py:208). */
 int ivr_rowwise_cosine(ivr_ctx *ctx, const float *a /*DEV*/, const float *b /*DEV*/, int n, int d, float *out /*DEV*/,
                        ivr_stream stream);
+
+/* ---- frame quality gating of the keyframe filter ---------------------------------------------------
+ * Replaces calculate_blur_score / calculate_edge_density at filter.py:63-92 (cv2.Laplacian(gray, CV_64F).var() and the share of
+ * cv2.Canny(gray, low, high) edge pixels) for a batch of decoded frames.  frames: DEV uint8 [n,h,w,3] (bgr = 1: cv2.imread
+ * order, 0: RGB).  lap_sums: DEV int64 [n,2] = (sum, sum of squares) of the integer Laplacian response over the frame - the
+ * variance is (s2 - s1*s1/N) / N with N = h*w, finished in float64 by the caller; edge_count: DEV int64 [n] = number of Canny
+ * edge pixels (edge density = 100 * count / N).  Scratch (5 bytes per pixel) lives in the context, per stream. */
+int64_t ivr_frame_quality_scratch_bytes(int n, int h, int w);
+int ivr_frame_quality(ivr_ctx *ctx, const uint8_t *frames /*DEV*/, int n, int h, int w, int bgr, int canny_low, int canny_high,
+                      int64_t *lap_sums /*DEV*/, int64_t *edge_count /*DEV*/, ivr_stream stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ constexpr int kDedupLds = 64 * 1024;   // two chunks
 
 template <int PER>      // floats of a row per lane: d <= 64 * PER
 __global__ __launch_bounds__(256) void dedup_kernel(const float *__restrict__ emb, int n, int d, float threshold,
-                                                    float *__restrict__ state, uint8_t *__restrict__ keep) {
+                                                    float *__restrict__ state, uint8_t *__restrict__ keep, int min_distance) {
     extern __shared__ __attribute__((aligned(16))) float buf[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rc = max(1, (kDedupLds / 2) / (d * 4));          // rows per chunk
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void dedup_kernel(const float *__restrict__ em
     float prev_ss = 0.f;
     int last_kept = -1;
     if (wave == 0) {
-        has_prev = state[0] != 0.f;
+        has_prev = state && state[0] != 0.f;             // state == NULL: a self-contained sequence (one scene)
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int k = lane + 64 * j;
@@ -80,6 +80,8 @@ __global__ __launch_bounds__(256) void dedup_kernel(const float *__restrict__ em
                     const float na = ss > 0.f ? sqrtf(ss) : 1.f, nb = prev_ss > 0.f ? sqrtf(prev_ss) : 1.f;
                     const float sim = dot / (na * nb);
                     if (sim >= threshold) uniq = false;
+                    // filter.py:196-198: a frame closer than min_frame_distance to the last kept one is never a candidate
+                    if (min_distance > 1 && last_kept >= 0 && r0 + r - last_kept < min_distance) uniq = false;
                 }
                 if (uniq) {                     // wave-uniform
                     has_prev = true;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void dedup_kernel(const float *__restrict__ em
         __syncthreads();
     }
     // carry the last kept embedding to the next batch
-    if (wave == 0 && last_kept >= 0) {
+    if (wave == 0 && last_kept >= 0 && state) {
 #pragma unroll
         for (int j = 0; j < PER; ++j)
             if (lane + 64 * j < d) state[1 + lane + 64 * j] = prev[j];
@@ -135,16 +137,16 @@ extern "C" int ivr_rowwise_cosine(ivr_ctx *ctx, const float *a, const float *b, 
     return IVR_OK;
 }
 
-extern "C" int ivr_dedup_keep_mask(ivr_ctx *ctx, const float *emb, int n, int d, float threshold, float *state,
-                                   uint8_t *keep, ivr_stream stream) {
-    IVR_REQUIRE(ctx && state && (n == 0 || (emb && keep)), "ivr_dedup_keep_mask: NULL argument");
-    IVR_REQUIRE(n >= 0 && d >= 1 && d <= 64 * kDedupMaxPer, "ivr_dedup_keep_mask: n=%d d=%d (d <= %d)", n, d, 64 * kDedupMaxPer);
+static int keep_chain(ivr_ctx *ctx, const float *emb, int n, int d, float threshold, float *state, uint8_t *keep, int min_distance,
+                      ivr_stream stream) {
+    IVR_REQUIRE(n >= 0 && d >= 1 && d <= 64 * kDedupMaxPer, "keep mask: n=%d d=%d (d <= %d)", n, d, 64 * kDedupMaxPer);
     if (n == 0) return IVR_OK;
     IVR_HIP(hipSetDevice(ctx->device));
     auto launch = [&](auto per) -> int {
         constexpr int PER = decltype(per)::value;
         if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(dedup_kernel<PER>), kDedupLds)) return rc;
-        hipLaunchKernelGGL(dedup_kernel<PER>, dim3(1), dim3(256), kDedupLds, (hipStream_t)stream, emb, n, d, threshold, state, keep);
+        hipLaunchKernelGGL(dedup_kernel<PER>, dim3(1), dim3(256), kDedupLds, (hipStream_t)stream, emb, n, d, threshold, state, keep,
+                           min_distance);
         return IVR_OK;
     };
     int rc;
@@ -156,4 +158,17 @@ extern "C" int ivr_dedup_keep_mask(ivr_ctx *ctx, const float *emb, int n, int d,
     if (rc != IVR_OK) return rc;
     IVR_LAUNCH_CHECK();
     return IVR_OK;
+}
+
+extern "C" int ivr_dedup_keep_mask(ivr_ctx *ctx, const float *emb, int n, int d, float threshold, float *state,
+                                   uint8_t *keep, ivr_stream stream) {
+    IVR_REQUIRE(ctx && state && (n == 0 || (emb && keep)), "ivr_dedup_keep_mask: NULL argument");
+    return keep_chain(ctx, emb, n, d, threshold, state, keep, 1, stream);
+}
+
+extern "C" int ivr_scene_keep_mask(ivr_ctx *ctx, const float *emb, int n, int d, float threshold, int min_distance, uint8_t *keep,
+                                   ivr_stream stream) {
+    IVR_REQUIRE(ctx && (n == 0 || (emb && keep)), "ivr_scene_keep_mask: NULL argument");
+    IVR_REQUIRE(min_distance >= 1, "ivr_scene_keep_mask: min_distance=%d", min_distance);
+    return keep_chain(ctx, emb, n, d, threshold, nullptr, keep, min_distance, stream);
 }

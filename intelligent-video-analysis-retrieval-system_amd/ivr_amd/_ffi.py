@@ -70,6 +70,9 @@ _SIGS = {
     "ivr_topk_merge": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "ivr_rowwise_cosine": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "ivr_dedup_keep_mask": (_i, [_p, _p, _i, _i, _f, _p, _p, _p]),
+    "ivr_scene_keep_mask": (_i, [_p, _p, _i, _i, _f, _i, _p, _p]),
+    "ivr_frame_quality_scratch_bytes": (_i64, [_i, _i, _i]),
+    "ivr_frame_quality": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -6,7 +6,7 @@
                        frames (excluding itself) with cosine > 0.7
 
 The cosines come from the HIP kernels (ivr_rowwise_cosine, the flat index self-search); the list bookkeeping is the
-reference's, kept on the host.  Blur / Canny gating (filter.py:63-92) needs OpenCV and stays out of scope.
+reference's, kept on the host.  Blur / edge-density gating (filter.py:63-92): ivr_amd/quality.py.
 """
 import ctypes as C
 
@@ -63,27 +63,19 @@ def group_into_scenes(transition_points, total_frames, min_length):
 
 def filter_similar_frames_in_scene(scene_embeddings, scene_indices, config):
     """filter.py:178: keep the first frame, then a frame at least `min_frame_distance` after the last kept one whose
-    cosine to it is below `similarity_threshold`; always keep the scene's last frame.  The scene's full cosine matrix
-    comes from one self-search-free GEMV batch on the device (scenes are short), the chain runs on the host."""
+    cosine to it is below `similarity_threshold`; always keep the scene's last frame.  The whole keep / drop chain of the
+    scene is ONE kernel launch (ivr_scene_keep_mask: the sequential chain of dedup.hip with the distance rule added) and
+    one copy of the mask back - not a launch and a sync per kept frame."""
     n = len(scene_embeddings)
     if not config["enable_similarity_filtering"] or n <= 1:
         return scene_indices
-    thr, min_dist = config["similarity_threshold"], config["min_frame_distance"]
+    thr, min_dist = float(config["similarity_threshold"]), max(1, int(config["min_frame_distance"]))
     e = _dev(np.asarray(scene_embeddings) if not isinstance(scene_embeddings, torch.Tensor) else scene_embeddings)
-    kept, last = [0], 0
-    i = 1
-    while i < n:
-        if i - last >= min_dist:
-            # cosines of every later candidate against the current anchor in one launch
-            cand = torch.arange(i, n, device=e.device)
-            sims = rowwise_cosine(e[cand], e[last].expand(len(cand), -1)).cpu().numpy()
-            hit = np.nonzero(sims < thr)[0]
-            if len(hit) == 0:
-                break
-            i = i + int(hit[0])
-            kept.append(i)
-            last = i
-        i += 1
+    keep = torch.empty(n, dtype=torch.uint8, device=e.device)
+    with torch.cuda.device(e.device):
+        _ffi.check(_ffi.load().ivr_scene_keep_mask(_ffi.context(e.device.index), C.c_void_p(e.data_ptr()), n, e.shape[1], thr, min_dist,
+                                                   C.c_void_p(keep.data_ptr()), _ffi.stream_ptr()), "ivr_scene_keep_mask")
+    kept = np.nonzero(keep.cpu().numpy())[0].tolist()
     if kept[-1] != n - 1:
         kept.append(n - 1)
     return [scene_indices[j] for j in kept]

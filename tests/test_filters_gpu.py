@@ -44,3 +44,17 @@ def test_similarity_graph_matches_oracle():
     assert got == want
     assert max(len(v) for v in got.values()) == 10 and all(k not in v for k, v in got.items())
     assert F.similarity_graph(feats[:1], keys[:1]) == {}
+
+
+def test_scene_filter_is_one_launch_and_handles_edge_rules():
+    """filter.py:178-222 corner cases against the line-by-line oracle: distance rule, nothing below the threshold (only first
+    and last survive), every frame distinct, two-frame scenes."""
+    from ivr_amd import filters as F
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal((30, 384)).astype(np.float32)
+    same = np.repeat(base[:1], 30, axis=0) + 1e-4 * rng.standard_normal((30, 384)).astype(np.float32)
+    for E in (base, same, _walk(9, 50, 384, 0.08), base[:2], same[:2]):
+        for thr, dist in ((0.95, 3), (0.95, 1), (0.5, 2), (1.01, 4), (-1.0, 2)):
+            cfg = {"enable_similarity_filtering": True, "similarity_threshold": thr, "min_frame_distance": dist}
+            idxs = list(range(100, 100 + len(E)))
+            assert F.filter_similar_frames_in_scene(E, idxs, cfg) == S.filter_similar_frames_in_scene(E, idxs, cfg), (len(E), thr, dist)
