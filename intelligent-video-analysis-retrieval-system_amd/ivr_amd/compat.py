@@ -272,36 +272,92 @@ class CLIPFeatureExtractor:
             return None
         return img
 
+    def _decode_many(self, image_paths):
+        """CPU decode on a worker pool (PIL releases the GIL while it decodes): [(path index, uint8 HWC array)] in path order,
+        unreadable / too-small images dropped with a warning (core.py:1597-1609)."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(ip):
+            i, p = ip
+            try:
+                im = self._load_and_validate_image(p)
+                return (i, np.asarray(im)) if im is not None else None
+            except Exception as e:
+                self.logger.warning("Failed to load image", path=p, error=str(e))
+                return None
+        workers = self.decode_workers or min(16, len(os.sched_getaffinity(0)))
+        if workers <= 1 or len(image_paths) < 4:
+            done = [one(ip) for ip in enumerate(image_paths)]
+        else:
+            with ThreadPoolExecutor(max_workers=workers) as ex:
+                done = list(ex.map(one, enumerate(image_paths), chunksize=8))
+        return [d for d in done if d is not None]
+
+    def _staging(self, nb, h, w, dev):
+        """Two pinned host buffers + two device buffers per (batch, frame size), kept across calls (pinning hundreds of MB costs
+        tens of milliseconds); the cache is dropped when it would pass 4 GiB."""
+        cache = self.__dict__.setdefault("_stage_cache", {})
+        key = (nb, h, w)
+        if key not in cache:
+            if sum(v[2] for v in cache.values()) + 4 * nb * h * w * 3 > (4 << 30):
+                cache.clear()
+            cache[key] = ([torch.empty((nb, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)],
+                          [torch.empty((nb, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(2)], 4 * nb * h * w * 3)
+        return cache[key][0], cache[key][1]
+
     def encode_images(self, image_paths: List[str], batch_size: int = 32, validate_files: bool = True,
-                      show_progress: bool = True) -> np.ndarray:
+                      show_progress: bool = True, return_kept: bool = False) -> np.ndarray:
+        """core.py:1556.  Decode on CPU workers, then every frame size present in the call goes to the GPU in batches of up to
+        `max_batch` frames: pinned double-buffered staging, H2D on a side stream under the previous batch's encode, resize + crop +
+        normalise + encode in HBM, ONE D2H of all embeddings at the end.  A folder of mixed sizes costs one launch chain per
+        (size, batch), not one per image.  return_kept=True also returns which inputs produced the rows (n may be < len(paths))."""
         if len(image_paths) == 0:
             raise ValueError("No image paths provided")
         if validate_files:
             image_paths = self._validate_image_paths(image_paths)
         if len(image_paths) == 0:
             raise ValueError("No valid image paths found")
-        # CPU decode (as in the reference), then same-sized frames go to the GPU together: resize + crop +
-        # normalise + encode run in HBM.  Unreadable / too-small images are dropped (n may be < len(paths)).
-        decoded = []
-        for p in image_paths:
-            try:
-                im = self._load_and_validate_image(p)
-                if im is not None:
-                    decoded.append(np.asarray(im))
-            except Exception as e:
-                self.logger.warning("Failed to load image", path=p, error=str(e))
+        decoded = self._decode_many(image_paths)
         if not decoded:
             raise RuntimeError("No images were successfully encoded")
-        out = np.empty((len(decoded), self.vision_model.embed_dim), dtype=np.float32)
+        n, D = len(decoded), self.vision_model.embed_dim
         by_shape: Dict[Tuple[int, int], List[int]] = {}
-        for i, a in enumerate(decoded):
-            by_shape.setdefault(a.shape[:2], []).append(i)
-        with self._lock:
-            for (h, w), idxs in by_shape.items():
-                batch = np.stack([decoded[i] for i in idxs])
+        for pos, (_, a) in enumerate(decoded):
+            by_shape.setdefault(a.shape[:2], []).append(pos)
+        dev = self.vision_model.device
+        mb = self.vision_model.max_batch
+        with self._lock, torch.cuda.device(dev):
+            out_dev = torch.empty((n, D), dtype=torch.float32, device=dev)
+            compute = torch.cuda.current_stream(dev)
+            copy = self._copy_stream = getattr(self, "_copy_stream", None) or torch.cuda.Stream(device=dev)
+            for (h, w), poss in by_shape.items():
                 mode = "identity" if (h, w) == (self.vision_config.image,) * 2 else "shortest_edge_crop"
-                emb = self.vision_model.encode_frames(batch, mode, C.CLIP_MEAN, C.CLIP_STD, normalize=True)
-                out[idxs] = emb.cpu().numpy()
+                nb = min(mb, len(poss))
+                host, devb = self._staging(nb, h, w, dev)
+                uploaded = [torch.cuda.Event() for _ in range(2)]      # H2D of buffer b finished (the pinned side may be refilled)
+                consumed = [torch.cuda.Event() for _ in range(2)]      # the encode that read device buffer b finished
+                used = [False, False]
+                for bi, b0 in enumerate(range(0, len(poss), nb)):
+                    sel = poss[b0:b0 + nb]
+                    b = bi & 1
+                    if used[b]:
+                        uploaded[b].synchronize()
+                    hv = host[b][:len(sel)].numpy()
+                    for r, pos in enumerate(sel):
+                        hv[r] = decoded[pos][1]
+                    with torch.cuda.stream(copy):
+                        if used[b]:
+                            copy.wait_event(consumed[b])
+                        devb[b][:len(sel)].copy_(host[b][:len(sel)], non_blocking=True)
+                        uploaded[b].record(copy)
+                    compute.wait_event(uploaded[b])
+                    emb = self.vision_model.encode_frames(devb[b][:len(sel)], mode, C.CLIP_MEAN, C.CLIP_STD, normalize=True)
+                    out_dev[torch.as_tensor(sel, device=dev)] = emb
+                    consumed[b].record(compute)
+                    used[b] = True
+            out = out_dev.cpu().numpy()
+        if return_kept:                      # positions (in image_paths after validation) of the rows returned, for the build driver
+            return out, [i for i, _ in decoded]
         return out
 
     def encode_frames(self, frames_u8, mode="identity", bgr=False):
@@ -534,14 +590,21 @@ class UnifiedIndex:
                  "resumed": False, "chunks_processed": 0}
         files = self._scan_files(keyframes_dir)
         stats["total_files"] = len(files)
-        vecs, metas = [], []
+        # rows go straight into one preallocated array (the reference's 2.2M-file build, logs/system_20250821.log:4, is 6.9 GB of
+        # 768-d rows: no per-row Python objects, no final np.stack copy)
+        V, nrows, metas = None, 0, []
         for c0 in range(0, len(files), chunk_size):
             chunk = files[c0:c0 + chunk_size]
             try:
-                feats = clip_processor.encode_images(chunk, validate_files=False, show_progress=False)
-                if len(feats) != len(chunk):
-                    raise RuntimeError("dropped images")
-                kept = chunk
+                try:                                         # this build's extractor says which files it dropped
+                    feats, pos = clip_processor.encode_images(chunk, validate_files=False, show_progress=False, return_kept=True)
+                    kept = [chunk[i] for i in pos]
+                    stats["failed_files"] += len(chunk) - len(kept)
+                except TypeError:                            # any duck-typed clip_processor with the reference's signature
+                    feats = clip_processor.encode_images(chunk, validate_files=False, show_progress=False)
+                    if len(feats) != len(chunk):
+                        raise RuntimeError("dropped images")
+                    kept = chunk
             except Exception:                                # fall back to per-file calls to find the bad ones
                 feats, kept = [], []
                 for p in chunk:
@@ -551,17 +614,22 @@ class UnifiedIndex:
                     except Exception:
                         stats["failed_files"] += 1
                 feats = np.stack(feats) if feats else np.zeros((0, 1), np.float32)
-            for p, f in zip(kept, feats):
+            if len(kept):
+                feats = np.asarray(feats, dtype=np.float32)
+                if V is None:
+                    V = np.empty((len(files), feats.shape[1]), dtype=np.float32)
+                V[nrows:nrows + len(kept)] = feats
+                nrows += len(kept)
+            for p in kept:
                 rel = os.path.relpath(p, keyframes_dir)
                 folder = os.path.dirname(rel) or os.path.basename(os.path.normpath(keyframes_dir))
                 metas.append({"folder_name": folder, "image_name": os.path.basename(p), "frame_id": _frame_id_of(p),
                               "file_path": p, "vector_index": len(metas)})
-                vecs.append(f)
             stats["processed_files"] += len(kept)
             stats["chunks_processed"] += 1
             if progress_callback:
                 progress_callback(stats["processed_files"], len(files))
-        V = np.stack(vecs).astype(np.float32) if vecs else np.zeros((0, 1), np.float32)
+        V = V[:nrows] if V is not None else np.zeros((0, 1), np.float32)
         np.savez(output_file if output_file.endswith(".npz") else output_file + ".npz", vectors=V,
                  metadata=np.frombuffer(json.dumps(metas).encode(), dtype=np.uint8),
                  csv_mappings=np.frombuffer(json.dumps(csv_mappings or {}).encode(), dtype=np.uint8))
