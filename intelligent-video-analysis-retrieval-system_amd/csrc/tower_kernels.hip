@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 // store tail is bound by the number of vector-memory instructions and the lines each one touches, not by bytes (s_memtime
 // stamps: 18.9k -> 6.3k cycles of a 55k-cycle qkv tile).  LDS images are XOR-swizzled by row: writes and reads are
 // conflict-free.
-template <typename T, int EPI, int ACT, bool SCALED = false, bool OUT8 = false>
+template <typename T, int EPI, int ACT, bool SCALED = false, bool OUT8 = false, bool SKIP = false>
 __device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4][8], unsigned char *wb, int row0, int col0, int lane) {
     const int r = lane & 15, gq = lane >> 4;
     float4 bv[4];
@@ -517,7 +517,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4]
                 for (int it = 0; it < 8; ++it) {
                     const int R = (b8 * 8 + it) * 4 + (lane >> 4), grow = row0 + half * 64 + R;
                     const float4 v = *reinterpret_cast<const float4 *>(wb + R * 256 + (((lane & 15) ^ (R & 15)) << 4));
-                    if (grow < g.M && !(g.skip_mod && grow % g.skip_mod == 0))
+                    if (grow < g.M && !(SKIP && grow % g.skip_mod == 0))
                         *reinterpret_cast<float4 *>(resp + (int64_t)grow * g.ldr) =
                             make_float4(rv[it].x + v.x, rv[it].y + v.y, rv[it].z + v.z, rv[it].w + v.w);
                 }
@@ -563,7 +563,9 @@ __device__ __forceinline__ void wait_vm_barrier() {
 constexpr int LBM = 256, LBN = 256, LX_BYTES = LBM * ROWB, LW_BYTES = LBN * ROWB;
 constexpr int DEEP_LDS = 3 * LX_BYTES + 2 * LW_BYTES;   // 160 KiB (bf16 / f32 kernel: three X slots, two W slots)
 
-template <typename T, int EPI, int ACT>
+// SKIP: EPI_RESID leaves rows r % skip_mod == 0 alone (a template parameter: the runtime test cost the plain instantiation 68 bytes
+// of scratch per lane)
+template <typename T, int EPI, int ACT, bool SKIP = false>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     IVR_STAMP(0)
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     if (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_RESID) && g.wide_epi) {
         __builtin_amdgcn_s_barrier();                         // every wave has read its last fragments
         if (n0 + wn * 64 < g.N)                               // N is a multiple of 64: a wave block is all in or all out
-            wide_epilogue<T, EPI, ACT>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
+            wide_epilogue<T, EPI, ACT, false, false, SKIP>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
 #ifdef IVR_GEMM_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         IVR_STAMP(3)
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
                     r.y += a[1] + bv[nt].y;
                     r.z += a[2] + bv[nt].z;
                     r.w += a[3] + bv[nt].w;
-                    if (mok[mt] && nok[nt] && !(EPI == EPI_RESID && g.skip_mod && mrow[mt] % g.skip_mod == 0))
+                    if (mok[mt] && nok[nt] && !(SKIP && mrow[mt] % g.skip_mod == 0))
                         *reinterpret_cast<float4 *>(rowp[mt] + ncol[nt]) = r;
                 }
         } else {
@@ -817,7 +819,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
 //     on W[nt]; the wait + barrier sits between G0 and G1 as in the bf16 kernel.
 //   * epilogue: acc * colscale[n] + bias[n] through the row-wide LDS-staged path (bf16, e4m3 or f32 residual output).
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int ACT, bool OUT8>
+template <int EPI, int ACT, bool OUT8, bool SKIP = false>
 __global__ __launch_bounds__(512, 2) void gemm_big8_kernel(GemmArgs g) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef int v8i __attribute__((ext_vector_type(8)));
@@ -951,7 +953,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big8_kernel(GemmArgs g) {
 #undef IVR_MMA8
     __builtin_amdgcn_s_barrier();                             // every wave has read its last fragments
     if (n0 + wn * 64 < g.N)
-        wide_epilogue<unsigned short, EPI, ACT, true, OUT8>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
+        wide_epilogue<unsigned short, EPI, ACT, true, OUT8, SKIP>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1918,7 +1920,13 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
         else if (EPI == EPI_RESID)
             ga.wide_epi = wide_env && bias_ok && g.N % 64 == 0 && g.ldr % 4 == 0 && reinterpret_cast<uintptr_t>(g.resid) % 16 == 0;
         const int grid = 8 * ((MT + 7) / 8) * NT;
-        hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT>), dim3(grid), dim3(512), DEEP_LDS, s, ga);
+        if (EPI == EPI_RESID && g.skip_mod) {
+            constexpr bool kSkip = EPI == EPI_RESID;
+            if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT, kSkip>), DEEP_LDS)) return rc;
+            hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT, kSkip>), dim3(grid), dim3(512), DEEP_LDS, s, ga);
+        } else {
+            hipLaunchKernelGGL((gemm_big_kernel<T, EPI, ACT>), dim3(grid), dim3(512), DEEP_LDS, s, ga);
+        }
         IVR_LAUNCH_CHECK();
         return IVR_OK;
     }
@@ -1968,7 +1976,13 @@ int launch_gemm8_t(const GemmArgs &g, hipStream_t s) {
     const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
     ga.group_m = group_env ? group_env : (NT <= 3 ? 2 : 4);
     ga.wide_epi = 1;
-    hipLaunchKernelGGL((gemm_big8_kernel<EPI, ACT, OUT8>), dim3(8 * ((MT + 7) / 8) * NT), dim3(512), DEEP_LDS, s, ga);
+    if (EPI == EPI_RESID && g.skip_mod) {
+        constexpr bool kSkip = EPI == EPI_RESID;
+        if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(gemm_big8_kernel<EPI, ACT, OUT8, kSkip>), DEEP_LDS)) return rc;
+        hipLaunchKernelGGL((gemm_big8_kernel<EPI, ACT, OUT8, kSkip>), dim3(8 * ((MT + 7) / 8) * NT), dim3(512), DEEP_LDS, s, ga);
+    } else {
+        hipLaunchKernelGGL((gemm_big8_kernel<EPI, ACT, OUT8>), dim3(8 * ((MT + 7) / 8) * NT), dim3(512), DEEP_LDS, s, ga);
+    }
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
