@@ -2041,7 +2041,7 @@ int ivr_launch_qkv_attention(const void *xn, const void *w, const float *bias, v
     g.T = T;
     g.heads = heads;
     g.G = 256 / T;
-    g.group_m = std::max(1, env_int("IVR_GEMM_GROUP_M", 4));
+    g.group_m = std::max(1, env_int("IVR_QKV_GROUP_M", 4));
     g.reverse = reverse;
     const int RT = g.G * T, MT = (M + RT - 1) / RT;
     const int grid = 8 * ((MT + 7) / 8) * heads;
