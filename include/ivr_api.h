@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define IVR_API_VERSION 2
+#define IVR_API_VERSION 3
 #define IVR_MAX_K 2048          /* reference: k=50 default, SearchOptions.limit <= 1000 (system.py:91) */
 
 typedef enum ivr_status {
@@ -126,6 +126,9 @@ typedef struct ivr_tower_desc {
      * (n rows per launch instead of n*tokens), the e4m3 GEMMs leave those residual rows alone.  Which assignment stays
      * inside which tolerance: DESIGN.md section 4, profiles/r02_fp8_error_budget.json. */
     int fp8_sites, fp8_mlp_cls_bf16;
+    /* IVR_COMPUTE_FP8 only: the mask applies to blocks fp8_first_layer .. layers-1, earlier blocks run in bf16 (the early
+     * blocks are the sensitive ones: their error passes through every later attention).  0 = every block. */
+    int fp8_first_layer;
 } ivr_tower_desc;
 
 int ivr_tower_create(ivr_ctx *ctx, const ivr_tower_desc *desc, ivr_tower **out);

@@ -33,7 +33,7 @@ struct ivr_tower {
     void *hid = nullptr;     // [rows, mlp]
     void *xn_cls = nullptr;  // [max_batch, D]   bf16 LN rows of token 0 (fp8 mode, fp8_mlp_cls_bf16)
     void *hid_cls = nullptr; // [max_batch, mlp] bf16 MLP hidden rows of token 0
-    int sites = 0;           // fp8 mode: effective IVR_FP8_SITE_* mask
+    int sites = 0;           // fp8 mode: effective IVR_FP8_SITE_* mask (blocks >= d.fp8_first_layer)
     bool mlp_cls = false;    // fp8 mode: token-0 rows take fc1 / fc2 in bf16
     void *pool = nullptr;    // [max_batch, D] pooled + LN rows (compute dtype)
     float *pooled_f32 = nullptr;   // [max_batch, D] (POOL_LN_ALL_CLS output before normalise)

@@ -28,8 +28,10 @@ int ivr_tower_create(ivr_ctx *ctx, const ivr_tower_desc *d, ivr_tower **out) {
                 "ivr_tower_create: the fp8 mode needs width and mlp to be multiples of 128 (width=%d mlp=%d)", d->width, d->mlp);
     IVR_REQUIRE(d->fp8_sites >= 0 && d->fp8_sites <= IVR_FP8_SITE_ALL && (d->fp8_mlp_cls_bf16 == 0 || d->fp8_mlp_cls_bf16 == 1),
                 "ivr_tower_create: fp8_sites=%d fp8_mlp_cls_bf16=%d", d->fp8_sites, d->fp8_mlp_cls_bf16);
-    IVR_REQUIRE(d->compute == IVR_COMPUTE_FP8 || (d->fp8_sites == 0 && d->fp8_mlp_cls_bf16 == 0),
-                "ivr_tower_create: fp8_sites / fp8_mlp_cls_bf16 only apply to IVR_COMPUTE_FP8");
+    IVR_REQUIRE(d->compute == IVR_COMPUTE_FP8 || (d->fp8_sites == 0 && d->fp8_mlp_cls_bf16 == 0 && d->fp8_first_layer == 0),
+                "ivr_tower_create: fp8_sites / fp8_mlp_cls_bf16 / fp8_first_layer only apply to IVR_COMPUTE_FP8");
+    IVR_REQUIRE(d->fp8_first_layer >= 0 && d->fp8_first_layer < d->layers, "ivr_tower_create: fp8_first_layer=%d outside [0,%d)",
+                d->fp8_first_layer, d->layers);
     if (d->kind == IVR_KIND_VISION) {
         IVR_REQUIRE(d->patch >= 1 && d->image % d->patch == 0, "ivr_tower_create: patch=%d image=%d", d->patch, d->image);
         const int g = d->image / d->patch;
@@ -216,8 +218,7 @@ int env_zigzag() {
 int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
     const ivr_tower_desc &d = t->d;
     const bool f32 = d.compute == IVR_COMPUTE_F32;
-    const bool q8 = t->sites & IVR_FP8_SITE_QKV, o8 = t->sites & IVR_FP8_SITE_ATTN_OUT, f18 = t->sites & IVR_FP8_SITE_FC1,
-               f28 = t->sites & IVR_FP8_SITE_FC2;
+
     // dtype of each site's A operand (LN output / attention output / MLP hidden): e4m3 where the consuming site is
     auto kind = [&](bool site8) { return f32 ? OUT_F32 : site8 ? OUT_FP8 : OUT_BF16; };
     const int D = d.width, rows = n * T;
@@ -230,6 +231,9 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
     int rc;
     for (int i = 0; i < d.layers; ++i) {
         const std::string p = "l" + std::to_string(i) + ".";
+        const int sites = i >= d.fp8_first_layer ? t->sites : 0;      // blocks in front of fp8_first_layer run in bf16
+        const bool q8 = sites & IVR_FP8_SITE_QKV, o8 = sites & IVR_FP8_SITE_ATTN_OUT, f18 = sites & IVR_FP8_SITE_FC1, f28 = sites & IVR_FP8_SITE_FC2;
+        const bool mlp_cls = t->mlp_cls && (f18 || f28);
         if (t->debug_out && t->debug_layer == i)
             IVR_HIP(hipMemcpyAsync(t->debug_out, t->resid, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s));
         rc = ivr_launch_layernorm(kind(q8), t->resid, 1, nullptr, wptr<float>(t, p + "ln1_g"), wptr<float>(t, p + "ln1_b"), d.ln_eps,
@@ -273,7 +277,7 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         rc = ivr_launch_layernorm(kind(f18), t->resid, 1, nullptr, wptr<float>(t, p + "ln2_g"), wptr<float>(t, p + "ln2_b"), d.ln_eps,
                                   t->xn, rows, D, s);
         if (rc) return rc;
-        if (t->mlp_cls) {                // token-0 rows of the same LayerNorm in bf16 for the side path
+        if (mlp_cls) {                   // token-0 rows of the same LayerNorm in bf16 for the side path
             rc = ivr_launch_layernorm(OUT_BF16, t->resid, T, nullptr, wptr<float>(t, p + "ln2_g"), wptr<float>(t, p + "ln2_b"), d.ln_eps,
                                       t->xn_cls, n, D, s);
             if (rc) return rc;
@@ -311,11 +315,11 @@ int run_layers(ivr_tower *t, int n, int T, hipStream_t s) {
         g.bias = wptr<float>(t, p + "fc2_b");
         g.resid = t->resid;
         g.ldr = D;
-        g.skip_mod = t->mlp_cls ? T : 0;
+        g.skip_mod = mlp_cls ? T : 0;
         g.tag = "gemm_fc2";
         rc = layer_gemm(t, f28, EPI_RESID, g, p + "fc2_w", s);
         if (rc) return rc;
-        if (t->mlp_cls) {
+        if (mlp_cls) {
             // side path: the n token-0 rows through fc1 / fc2 in bf16 (rows of image i sit T*D apart in the residual stream)
             g = GemmArgs();
             g.A = t->xn_cls;
@@ -452,7 +456,7 @@ int ivr_tower_finalize(ivr_tower *t, int max_batch) {
                      {"fc1_w", H(p + "fc1_w").data(), d.mlp, D, IVR_FP8_SITE_FC1, t->mlp_cls},
                      {"fc2_w", H(p + "fc2_w").data(), D, d.mlp, IVR_FP8_SITE_FC2, t->mlp_cls}};
         for (const auto &st : site) {
-            const bool s8 = t->sites & st.bit;
+            const bool s8 = i >= d.fp8_first_layer && (t->sites & st.bit);
             if (s8 && (rc = upload_fp8(t, p + st.name, st.host, st.N, st.K))) return rc;
             if ((!s8 || st.also_bf16) && (rc = upload(t, p + st.name, st.host, st.N * st.K, true))) return rc;
         }

@@ -22,10 +22,11 @@ PP_BGR, PP_OUT_F32, PP_OUT_PATCH_MAJOR, PP_BILINEAR = 1 << 4, 1 << 5, 1 << 6, 1 
 class TowerDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("kind", "width", "layers", "heads", "mlp", "tokens", "out_dim", "act", "pool",
                                        "image", "patch", "pre_ln", "patch_bias", "vocab", "eos_id", "causal",
-                                       "compute")] + [("ln_eps", C.c_float), ("fp8_sites", C.c_int), ("fp8_mlp_cls_bf16", C.c_int)]
+                                       "compute")] + [("ln_eps", C.c_float), ("fp8_sites", C.c_int), ("fp8_mlp_cls_bf16", C.c_int),
+                                                                      ("fp8_first_layer", C.c_int)]
 
 
-API_VERSION = 2
+API_VERSION = 3
 FP8_SITE = {"qkv": 1, "o": 2, "fc1": 4, "fc2": 8}
 
 

@@ -9,7 +9,9 @@ linear sites of every block to e4m3 with one scale per output channel:
   compute="fp8"      the MLP sites (fc1, fc2 = two thirds of the FLOPs) in e4m3, the token-0 rows of those sites on a bf16
                      side path: the assignment that keeps 1 - cos(embedding, f32 embedding) <= 1e-3
   compute="fp8_all"  all four sites (qkv, attn-out, fc1, fc2) in e4m3: fastest, 1 - cos ~ 4e-3 (3 mantissa bits)
-  fp8_sites=(...), fp8_cls_bf16=...  explicit assignment (tools/fp8_error_budget*.py)
+  compute="fp8_strict"  as "fp8" but only in the last third of the blocks (the early blocks' error passes through every later
+                     attention): the assignment that keeps |score - f32 score| <= 1e-3 against unrelated (text) queries too
+  fp8_sites=(...), fp8_cls_bf16=..., fp8_first_layer=...  explicit assignment (tools/fp8_error_budget.py)
 """
 import ctypes as C
 
@@ -22,23 +24,29 @@ from .preprocess import preprocess_frames
 
 
 class Tower:
-    def __init__(self, cfg: TowerConfig, weights, max_batch=256, compute="bf16", device=None, fp8_sites=None, fp8_cls_bf16=None):
+    def __init__(self, cfg: TowerConfig, weights, max_batch=256, compute="bf16", device=None, fp8_sites=None, fp8_cls_bf16=None,
+                 fp8_first_layer=None):
         self._lib = _ffi.load()
         self.cfg = cfg
         self.compute = compute
-        sites, cls = 0, 0
-        if compute in ("fp8", "fp8_all"):
+        sites, cls, first = 0, 0, 0
+        if compute in ("fp8", "fp8_all", "fp8_strict"):
             if fp8_sites is None:
-                fp8_sites = ("fc1", "fc2") if compute == "fp8" else ("qkv", "o", "fc1", "fc2")
+                fp8_sites = ("qkv", "o", "fc1", "fc2") if compute == "fp8_all" else ("fc1", "fc2")
             if fp8_cls_bf16 is None:
-                fp8_cls_bf16 = compute == "fp8"
+                fp8_cls_bf16 = compute != "fp8_all"
+            if fp8_first_layer is None:
+                fp8_first_layer = (2 * cfg.layers) // 3 if compute == "fp8_strict" else 0
+            first = int(fp8_first_layer)
+            if not 0 <= first < cfg.layers:
+                raise ValueError(f"fp8_first_layer={first} outside [0,{cfg.layers})")
             sites = sum(_ffi.FP8_SITE[s] for s in set(fp8_sites))
             if sites == 0:
                 raise ValueError("fp8_sites is empty: use compute='bf16'")
             cls = int(bool(fp8_cls_bf16))
-        elif fp8_sites is not None or fp8_cls_bf16 is not None:
-            raise ValueError("fp8_sites / fp8_cls_bf16 only apply to compute='fp8' / 'fp8_all'")
-        self.fp8_sites, self.fp8_cls_bf16 = sites, cls
+        elif fp8_sites is not None or fp8_cls_bf16 is not None or fp8_first_layer is not None:
+            raise ValueError("fp8_sites / fp8_cls_bf16 / fp8_first_layer only apply to compute='fp8' / 'fp8_all' / 'fp8_strict'")
+        self.fp8_sites, self.fp8_cls_bf16, self.fp8_first_layer = sites, cls, first
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
         self.max_batch = int(max_batch)
         # patch-major pixels stay bf16 in the fp8 mode (only the four GEMMs of every block run on the fp8 MFMA)
@@ -47,8 +55,8 @@ class Tower:
                            mlp=cfg.mlp, tokens=cfg.tokens, out_dim=cfg.out_dim, act=cfg.act, pool=cfg.pool,
                            image=cfg.image, patch=cfg.patch, pre_ln=int(cfg.pre_ln), patch_bias=int(cfg.patch_bias),
                            vocab=cfg.vocab, eos_id=cfg.eos_id, causal=int(cfg.causal),
-                           compute={"bf16": 0, "f32": 1, "fp8": 2, "fp8_all": 2}[compute], ln_eps=cfg.ln_eps,
-                           fp8_sites=sites, fp8_mlp_cls_bf16=cls)
+                           compute={"bf16": 0, "f32": 1, "fp8": 2, "fp8_all": 2, "fp8_strict": 2}[compute], ln_eps=cfg.ln_eps,
+                           fp8_sites=sites, fp8_mlp_cls_bf16=cls, fp8_first_layer=first)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _ffi.check(self._lib.ivr_tower_create(_ffi.context(self.device.index), C.byref(d), C.byref(h)),

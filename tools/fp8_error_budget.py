@@ -58,6 +58,7 @@ def main():
     Sref = np.concatenate([ref[args.frames:], tref]) @ ref[:args.frames].T
 
     def measure(spec):
+        nonlocal tq
         emb = QR.vision_forward(vcfg, wv, px, spec)
         cos = (emb * ref).sum(1)
         S = np.concatenate([emb[args.frames:], tq]) @ emb[:args.frames].T
@@ -93,6 +94,23 @@ def main():
         spec = QR.QuantSpec(sub, keep_rows=(0,))
         spec.keep_sites = {"fc1", "fc2"}
         run(f"e4m3 {'+'.join(sub)} / token-0 rows of fc1, fc2 in bf16", spec)
+    # ... and only from block `first` on (tower desc fp8_first_layer): compute="fp8_strict" is first = 2L/3
+    if not args.quick:
+        L = vcfg.layers
+        for first in (L // 3, L // 2, (2 * L) // 3, (5 * L) // 6):
+            spec = QR.QuantSpec(("fc1", "fc2"), fp8_layers=range(first, L), keep_rows=(0,))
+            spec.keep_sites = {"fc1", "fc2"}
+            run(f"e4m3 fc1+fc2 in blocks [{first},{L}) / token-0 rows in bf16", spec)
+        # text queries from the float32 text tower instead of the bf16 one (queries are few)
+        tq_saved = tq
+        tq = tref
+        for label, spec in (("bf16 (all sites), f32 text tower", QR.QuantSpec((), base="bf16")),
+                            (f"e4m3 fc1+fc2 in blocks [{(2 * L) // 3},{L}) / token-0 rows in bf16, f32 text tower",
+                             QR.QuantSpec(("fc1", "fc2"), fp8_layers=range((2 * L) // 3, L), keep_rows=(0,))),
+                            ("e4m3 fc1+fc2 / token-0 rows in bf16, f32 text tower", QR.QuantSpec(("fc1", "fc2"), keep_rows=(0,)))):
+            spec.keep_sites = {"fc1", "fc2"}
+            run(label, spec)
+        tq = tq_saved
     out = {"tower": vcfg.name, "frames": args.frames, "image_queries": args.image_queries, "text_queries": args.text_queries,
            "bound": "north_star: |score - f32 score| <= 1e-3", "rows": rows,
            "method": "oracle/quant_ref.py: operand rounding emulated on the CPU, float32 accumulation"}
