@@ -168,7 +168,7 @@ class CLIPFeatureExtractor:
 
     def __init__(self, model_path="openai/clip-vit-large-patch14", config=None, logger=None, weights=None,
                  text_weights=None, tokenizer=None, max_batch=256, compute="bf16", seed=0, with_text=True,
-                 allow_random_init=False, decode_workers=None):
+                 allow_random_init=False, decode_workers=None, text_compute="f32"):
         self.config = config
         self.logger = logger or _NullLogger()
         self.model_path = model_path
@@ -211,7 +211,10 @@ class CLIPFeatureExtractor:
         self.text_model = None
         if with_text:
             tw = self._resolve(txt_cfg, text_weights, seed + 1)
-            self.text_model = Tower(txt_cfg, tw, max_batch=64, compute="bf16" if compute.startswith("fp8") else compute)
+            # Queries are a handful of rows per search (core.py:1504 encodes one string): the float32 tower costs microseconds more
+            # and keeps text-vs-image scores within the 1e-3 bound - the bf16 text tower alone moves them by up to 1.1e-3
+            # (DESIGN.md section 4, fp8 table).  text_compute="bf16" restores the fast mode for bulk text encoding.
+            self.text_model = Tower(txt_cfg, tw, max_batch=64, compute=text_compute)
         self.model = self.vision_model    # truthy: health check at system.py:263
         if tokenizer is None and isinstance(model_path, str) and os.path.isfile(os.path.join(model_path, "vocab.json")):
             try:                          # the checkpoint's own BPE tokenizer, local files only

@@ -70,6 +70,12 @@ def test_encode_images_matches_oracle_and_drops_bad_files(extractor, keyframes):
     assert extractor.model and extractor.encode_text(["test"], validate_input=False).shape == (1, 512)   # system.py:263-270
     with pytest.raises(ValueError):
         extractor.encode_text(["   "])
+    # text queries go through the float32 text tower by default (a handful of rows per search): oracle-exact to 2e-5
+    texts = ["a red car", "two dogs on a beach"]
+    ids = extractor.processor(texts, max_length=77)
+    ref_t = V.text_forward(C.CLIP_TEXT_B32, make_weights(C.CLIP_TEXT_B32, 4), ids)        # text weights: seed + 1
+    got_t = extractor.encode_text(texts)
+    assert got_t.shape == (2, 512) and np.abs(got_t - ref_t).max() < 2e-5
 
 
 def test_legacy_build_and_search_conventions(extractor, keyframes):
