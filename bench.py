@@ -116,8 +116,18 @@ def side_configs(dev, weights_b32):
             for _ in range(2):
                 index.search_device(q, 10, normalize=True)
             ms = timed(lambda: index.search_device(q, 10, normalize=True), 5)
+            # parity at full size on a sample: 8 of the 1000 queries against the float64 oracle over the rows the device holds
+            from oracle import search_ref as S
+            Dq, Iq = index.search_device(q, 10, normalize=True)
+            pick = np.arange(0, 1000, 125)
+            Xh = index.reconstruct_n(0, 1_250_000)
+            qn = S.normalize_rows_core(q[pick].cpu().numpy()).astype(np.float32)
+            Dr, Ir = S.flat_ip_search(Xh, qn, 10, dtype=np.float64)
             out["configs2_one_shard"] = {"rows": 1_250_000, "queries": 1000, "k": 10, "search_ms": ms,
-                                         "pairs_per_s": 1_250_000 * 1000 / (ms * 1e-3)}
+                                         "pairs_per_s": 1_250_000 * 1000 / (ms * 1e-3),
+                                         "ids_exact_on_sample_of_8_queries": bool(np.array_equal(Iq[pick].cpu().numpy(), Ir)),
+                                         "max_abs_score_err_on_sample": float(np.abs(Dq[pick].cpu().numpy() - Dr).max())}
+            del Xh
     cfg = C.CLIP_VIT_B32
     tower = Tower(cfg, weights_b32, max_batch=8, device=dev.index)
     queries = torch.from_numpy(np.random.default_rng(91011).standard_normal((10, 512), dtype=np.float32))
