@@ -18,6 +18,7 @@
 //            64-bit keys (ordered score, ~row).
 //   pass 4   per query, radix-select + bitonic sort of the k best keys -> D (float32), I (int64).
 #include "ivr_common.h"
+#include "search_internal.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict_
                                                         int normalize, int32_t *__restrict__ nonfinite,
                                                         const int64_t *__restrict__ start_dev, uint4 *__restrict__ dst16,
                                                         uint4 *__restrict__ dst16lo, unsigned int *__restrict__ maxnorm_bits,
-                                                        float *__restrict__ rownorm, int zero_fill) {
+                                                        float *__restrict__ rownorm, int zero_fill, int pstride,
+                                                        unsigned int *__restrict__ maxdelta_bits, float *__restrict__ rowdelta) {
     if (start_dev) row_start = *start_dev;          // ring cursor kept in HBM so a captured graph can replay it
     const int lane = threadIdx.x & 63;
     const int64_t tile0 = row_start >> 4;
@@ -110,8 +112,9 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict_
     // normalised, as for the index rows above)
     if (rownorm && valid && qd == 0) rownorm[row - row_start] = normalize ? (ss > 0.f ? 1.000001f : 0.f) : sqrtf(ss);
     float4 *out = reinterpret_cast<float4 *>(dst) + tile * (int64_t)dp4 * 16 + lane;
-    const int pieces = (kchunks + 1) >> 1;
+    const int pieces = (kchunks + 1) >> 1;          // pieces that carry data; the tile's stride is pstride (even, see ivr_index_create)
     const bool store = valid || zero_fill;          // query tiles: the padding rows of the last tile are written as zeros
+    float sd = 0.f;                                 // squared norm of this lane's part of  row - bf16(row)
     for (int kb0 = 0; kb0 < pieces; kb0 += 4) {
       float4 vv[4][2];
 #pragma unroll
@@ -146,20 +149,37 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float *__restrict_
             hi.y = ivr_pack_bf16x2(v[0].z, v[0].w);
             hi.z = ivr_pack_bf16x2(v[1].x, v[1].y);
             hi.w = ivr_pack_bf16x2(v[1].z, v[1].w);
-            dst16[(tile * pieces + kb) * 64 + lane] = hi;
-            if (dst16lo) {
-                auto lo2 = [](uint32_t h, float a, float b) {
-                    return ivr_pack_bf16x2(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
-                };
-                uint4 lo;
-                lo.x = lo2(hi.x, v[0].x, v[0].y);
-                lo.y = lo2(hi.y, v[0].z, v[0].w);
-                lo.z = lo2(hi.z, v[1].x, v[1].y);
-                lo.w = lo2(hi.w, v[1].z, v[1].w);
-                dst16lo[(tile * pieces + kb) * 64 + lane] = lo;
-            }
+            dst16[(tile * pstride + kb) * 64 + lane] = hi;
+            // what rounding to bf16 dropped: exact in float32 (the difference of a float and its own leading bits)
+            auto lo2 = [&sd](uint32_t h, float a, float b) {
+                const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+                sd = fmaf(ra, ra, sd);
+                sd = fmaf(rb, rb, sd);
+                return ivr_pack_bf16x2(ra, rb);
+            };
+            uint4 lo;
+            lo.x = lo2(hi.x, v[0].x, v[0].y);
+            lo.y = lo2(hi.y, v[0].z, v[0].w);
+            lo.z = lo2(hi.z, v[1].x, v[1].y);
+            lo.w = lo2(hi.w, v[1].z, v[1].w);
+            if (dst16lo) dst16lo[(tile * pstride + kb) * 64 + lane] = lo;
         }
       }
+    }
+    // |row - bf16(row)| per stored row, for the error bound of the large-batch candidate scan (both operands rounded to nearest):
+    // the largest over the index rows, one value per query
+    if (dst16 && (maxdelta_bits || rowdelta)) {
+        sd += __shfl_xor(sd, 16, 64);
+        sd += __shfl_xor(sd, 32, 64);
+        float dl = valid ? sqrtf(sd) * 1.0001f : 0.f;
+        if (!(dl == dl)) dl = INFINITY;             // NaN rows: no bound, every verification fails over to the exact path
+        if (rowdelta && valid && qd == 0) rowdelta[row - row_start] = dl;
+        if (maxdelta_bits) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) dl = fmaxf(dl, __shfl_xor(dl, o, 64));
+            const unsigned int bits = __float_as_uint(dl);
+            if (lane == 0 && bits > *maxdelta_bits) atomicMax(maxdelta_bits, bits);
+        }
     }
 }
 
@@ -260,22 +280,11 @@ __device__ __forceinline__ void score_group(const float4 *__restrict__ a, int64_
 }
 
 // pass 1.  gmax layout: [16*QT queries][mstride groups]
+// the wave loop of the exact scan: every 64-row group against the 16*QT queries staged in qs
 template <int QT>
-__global__ __launch_bounds__(512) void scan_groupmax_kernel(const float *__restrict__ data,
-                                                            const float *__restrict__ qtiled, int dp4,
-                                                            int64_t ngroups, int64_t ntotal,
-                                                            float *__restrict__ gmax, int64_t mstride,
-                                                            const int *__restrict__ tile_flag) {
-    extern __shared__ __attribute__((aligned(16))) float4 qs[];
-    if (tile_flag) {       // fallback pass behind the bf16 candidate scan: only query tiles that failed their verification
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < QT; ++i) any |= tile_flag[i] != 0;
-        if (!any) return;
-    }
+__device__ __forceinline__ void scan_groups_body(const float4 *__restrict__ qs, const float *__restrict__ data, int dp4, int64_t ngroups,
+                                                 int64_t ntotal, float *__restrict__ gmax, int64_t mstride) {
     const int per_tile = dp4 * 16;   // float4 per 16-row tile
-    for (int i = threadIdx.x; i < QT * per_tile; i += blockDim.x) qs[i] = reinterpret_cast<const float4 *>(qtiled)[i];
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int kchunks = dp4 >> 2;
     auto bload = [&](int q, int kc) { return qs[q * per_tile + kc * 64 + lane]; };
@@ -299,6 +308,54 @@ __global__ __launch_bounds__(512) void scan_groupmax_kernel(const float *__restr
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             if (lane < 16) gmax[(int64_t)(q * 16 + lane) * mstride + g] = m;
         }
+    }
+}
+
+template <int QT>
+__global__ __launch_bounds__(512) void scan_groupmax_kernel(const float *__restrict__ data,
+                                                            const float *__restrict__ qtiled, int dp4,
+                                                            int64_t ngroups, int64_t ntotal,
+                                                            float *__restrict__ gmax, int64_t mstride,
+                                                            const int *__restrict__ tile_flag) {
+    extern __shared__ __attribute__((aligned(16))) float4 qs[];
+    if (tile_flag) {       // fallback pass behind the bf16 candidate scan: only query tiles that failed their verification
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < QT; ++i) any |= tile_flag[i] != 0;
+        if (!any) return;
+    }
+    const int per_tile = dp4 * 16;
+    for (int i = threadIdx.x; i < QT * per_tile; i += blockDim.x) qs[i] = reinterpret_cast<const float4 *>(qtiled)[i];
+    __syncthreads();
+    scan_groups_body<QT>(qs, data, dp4, ngroups, ntotal, gmax, mstride);
+}
+
+// Exact pass behind the LARGE-batch candidate scan: the queries whose verification failed were appended to `list` by the final
+// selection (count = *nlist, known on the device only).  Each chunk of 16*QT listed queries is gathered from the tiled query
+// buffer straight into LDS (element (kc, lane) of a staged tile = the float4 of query (lane & 15), quad (lane >> 4), chunk kc)
+// and scanned like any other; nothing listed: every workgroup exits at once.  gmax row = position in the list.
+template <int QT>
+__global__ __launch_bounds__(512) void scan_groupmax_list_kernel(const float *__restrict__ data, const float *__restrict__ qtiled,
+                                                                 int dp4, int64_t ngroups, int64_t ntotal, float *__restrict__ gmax,
+                                                                 int64_t mstride, const int *__restrict__ nlist,
+                                                                 const int *__restrict__ list) {
+    extern __shared__ __attribute__((aligned(16))) float4 qs[];
+    const int nf = *nlist;
+    const int per_tile = dp4 * 16;
+    for (int c0 = 0; c0 < nf; c0 += 16 * QT) {
+        __syncthreads();                               // the previous chunk's waves are done with qs
+        for (int i = threadIdx.x; i < QT * per_tile; i += blockDim.x) {
+            const int t = i / per_tile, r = i - t * per_tile, l = r & 63;
+            const int pos = c0 + t * 16 + (l & 15);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos < nf) {
+                const int src = list[pos];
+                v = reinterpret_cast<const float4 *>(qtiled)[(int64_t)(src >> 4) * per_tile + (r - l) + (l & 48) + (src & 15)];
+            }
+            qs[i] = v;
+        }
+        __syncthreads();
+        scan_groups_body<QT>(qs, data, dp4, ngroups, ntotal, gmax + (int64_t)c0 * mstride, mstride);
     }
 }
 
@@ -397,33 +454,54 @@ struct VerifyArgs {
     const unsigned int *maxnorm_bits = nullptr;
     int *ok = nullptr;                    // NULL = no verification in this launch
     int *tile_flag = nullptr;
+    // large-batch scan (scanq_kernel: both operands rounded to bf16): the bound uses the measured rounding residuals,
+    //   |approx - exact| <= (|q| + |dq|) max|dr| + |dq| max|r| + acc_eps |q| max|r|,   dq = q - bf16(q), dr = row - bf16(row);
+    // a failed query is appended to fail_list (its exact pass is list-driven, scan_groupmax_list_kernel)
+    const float *qdelta = nullptr;        // non-NULL selects this mode
+    const unsigned int *maxdelta_bits = nullptr;
+    float acc_eps = 0.f;
+    int *fail_count = nullptr, *fail_list = nullptr;
+};
+
+// list-driven launches (the exact pass behind the large-batch scan): block b works on list position b and exits when
+// b >= *count; results go to output row list[b]
+struct ListArgs {
+    const int *count = nullptr;
+    const int *list = nullptr;
 };
 
 // pass 3: one wave per (query, selected group, 16-row tile).  cand[q][j*64 + row] = key(score, row id).
 // A tile's accumulator sees exactly the MFMA sequence it sees in score_group (ascending K, x y z w per chunk), so the scores are
 // bit-identical to pass 1; splitting the group over four waves and keeping 16 KiB of the tile in flight per wave is what makes
 // this pass short: it is a latency chain of k x 64 rows per query, not a bandwidth problem.
+// TILES: the selection holds 16-row tiles instead of 64-row groups (large-batch scan): one wave per (query, selected tile),
+// cand[q][j*16 + row].  qmap (list-driven exact pass): query q of this launch is the list's q-th entry, qmap[q] in the tiled
+// query buffer; waves past *qcount exit.
+template <bool TILES>
 __global__ __launch_bounds__(256) void rescore_groups_kernel(const float *__restrict__ data,
                                                              const float *__restrict__ qtiled, int dp4,
                                                              int64_t ntotal, const uint32_t *__restrict__ sel,
                                                              int sel_stride, int ksel, int nq, uint64_t *__restrict__ cand,
-                                                             const int *__restrict__ skip) {
+                                                             const int *__restrict__ skip, ListArgs la) {
+    constexpr int kRows = TILES ? 16 : kGroupRows, kSplit = TILES ? 1 : 4;
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= (int64_t)nq * ksel * 4) return;
-    const int t = (int)(w & 3);
-    const int64_t qj = w >> 2;
+    if (w >= (int64_t)nq * ksel * kSplit) return;
+    const int t = TILES ? 0 : (int)(w & 3);
+    const int64_t qj = TILES ? w : w >> 2;
     const int q = (int)(qj / ksel), j = (int)(qj % ksel);
     if (skip && skip[q]) return;
+    if (la.count && q >= *la.count) return;
+    const int qs = la.list ? la.list[q] : q;       // row of the tiled query buffer
     const uint32_t g = sel[(int64_t)q * sel_stride + j];
-    uint64_t *out = cand + ((int64_t)q * ksel + j) * kGroupRows + t * 16;
+    uint64_t *out = cand + ((int64_t)q * ksel + j) * kRows + t * 16;
     if (g == 0xFFFFFFFFu) {   // fewer groups than k
         if (lane < 16) out[lane] = 0;
         return;
     }
     const int per_tile = dp4 * 16, kchunks = dp4 >> 2;
-    const float4 *b = reinterpret_cast<const float4 *>(qtiled) + (int64_t)(q >> 4) * per_tile + lane;
-    const float4 *a = reinterpret_cast<const float4 *>(data) + ((int64_t)g * 4 + t) * per_tile + lane;
+    const float4 *b = reinterpret_cast<const float4 *>(qtiled) + (int64_t)(qs >> 4) * per_tile + lane;
+    const float4 *a = reinterpret_cast<const float4 *>(data) + ((int64_t)g * kSplit + t) * per_tile + lane;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int kc = 0;
     for (; kc + 16 <= kchunks; kc += 16) {
@@ -447,11 +525,11 @@ __global__ __launch_bounds__(256) void rescore_groups_kernel(const float *__rest
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
     }
-    if ((lane & 15) == (q & 15)) {
+    if ((lane & 15) == (qs & 15)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rl = (lane >> 4) * 4 + r;
-            const int64_t row = (int64_t)g * kGroupRows + t * 16 + rl;
+            const int64_t row = (int64_t)g * kRows + t * 16 + rl;
             uint64_t key = 0;
             if (row < ntotal) key = ((uint64_t)ivr_f2ord(acc[r]) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)row);
             out[rl] = key;
@@ -469,6 +547,21 @@ struct SrcGroupMax {   // pass 2: keys from the group-maximum column of query q
     __device__ uint64_t key(int q, int64_t i) const {
         return ((uint64_t)ivr_f2ord(gmax[(int64_t)q * mstride + i]) << 32) |
                (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+    }
+};
+struct SrcTilesOf {    // large-batch scan, second level: the 16-row tile maxima of the 128-row blocks selected at the first level
+    const float *tmax;
+    int64_t tstride;
+    const uint32_t *selb;      // [nq][kb] selected blocks (0xFFFFFFFF = none)
+    int kb;
+    int64_t ntiles;            // ceil(ntotal / 16)
+    int64_t n;                 // kb * 8
+    __device__ uint64_t key(int q, int64_t i) const {
+        const uint32_t b = selb[(int64_t)q * kb + (i >> 3)];
+        if (b == 0xFFFFFFFFu) return 0;
+        const int64_t t = (int64_t)b * 8 + (i & 7);
+        if (t >= ntiles) return 0;
+        return ((uint64_t)ivr_f2ord(tmax[(int64_t)q * tstride + t]) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)t);
     }
 };
 struct SrcKeys {       // pass 4: keys already materialised
@@ -499,9 +592,10 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
                                                                   float *__restrict__ D, int64_t *__restrict__ I,
                                                                   const int64_t *__restrict__ I_parts,
                                                                   const int *__restrict__ skip = nullptr, VerifyArgs vf = VerifyArgs(),
-                                                                  int *__restrict__ reset_flags = nullptr) {
+                                                                  int *__restrict__ reset_flags = nullptr, ListArgs la = ListArgs()) {
     if (reset_flags && blockIdx.x == 0 && threadIdx.x < 4) reset_flags[threadIdx.x] = 0;
     if (skip && skip[blockIdx.x]) return;          // whole block: this query kept its fast-path result
+    if (la.count && (int)blockIdx.x >= *la.count) return;
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix, s_mask;
     __shared__ unsigned int s_kth, s_cnt, s_valid;
@@ -694,7 +788,8 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
         if (OUT == OUT_GROUPS) {
             out_groups[(int64_t)q * k + j] = key ? low : 0xFFFFFFFFu;
         } else {
-            D[(int64_t)q * k + j] = key ? ivr_ord2f((uint32_t)(key >> 32)) : -FLT_MAX;
+            const int64_t qo = la.list ? la.list[q] : q;     // output row
+            D[qo * k + j] = key ? ivr_ord2f((uint32_t)(key >> 32)) : -FLT_MAX;
             int64_t id = -1;
             if (key) {
                 if (OUT == OUT_DI_PARTS) {
@@ -704,19 +799,30 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
                     id = id_base + (int64_t)low;
                 }
             }
-            I[(int64_t)q * k + j] = id;
+            I[qo * k + j] = id;
         }
     }
     if (OUT == OUT_DI && vf.ok && tid == 0) {
         const uint32_t g = vf.sel[(int64_t)q * vf.ksel2 + vf.kp];
         int good = 1;
         if (g != 0xFFFFFFFFu) {                       // there IS an excluded group
-            const float bound = vf.gmax[(int64_t)q * vf.mstride + g] + vf.rel_eps * vf.qnorm[q] * __uint_as_float(*vf.maxnorm_bits);
+            const float rmax = __uint_as_float(*vf.maxnorm_bits);
+            float e;
+            if (vf.qdelta) {
+                const float qn = vf.qnorm[q], qd = vf.qdelta[q];
+                e = 1.01f * ((qn + qd) * __uint_as_float(*vf.maxdelta_bits) + qd * rmax + vf.acc_eps * qn * rmax);
+            } else {
+                e = vf.rel_eps * vf.qnorm[q] * rmax;
+            }
+            const float bound = vf.gmax[(int64_t)q * vf.mstride + g] + e;
             const float kth = (int)keff >= k ? ivr_ord2f((uint32_t)(sorted[k - 1] >> 32)) : -FLT_MAX;
             good = bound < kth;                        // false for NaN / inf bounds too
         }
         vf.ok[q] = good;
-        if (!good) atomicOr(&vf.tile_flag[q >> 4], 1);
+        if (!good) {
+            if (vf.fail_list) vf.fail_list[atomicAdd(vf.fail_count, 1)] = q;
+            else atomicOr(&vf.tile_flag[q >> 4], 1);
+        }
     }
 }
 
@@ -748,6 +854,17 @@ struct ivr_index {
     unsigned int *maxnorm = nullptr; // DEV: bits of the largest stored row norm
     int *okflag = nullptr;           // DEV [64] per scan chunk + [4] tile flags behind it
     int last_nqc = 0;                // queries of the last chunk that went through the candidate scan
+    // large-batch candidate scan (search_scanq.hip): more than 64 queries per call
+    unsigned int *maxdelta = nullptr;// DEV: bits of the largest |row - bf16(row)| over the stored rows
+    float *qdelta = nullptr;         // DEV [qtiles*16]: |q - bf16(q)| of each tiled query
+    float *tmax = nullptr;           // DEV [padded queries of a chunk][tstride]: 16-row tile maxima (also the gmax of its exact pass)
+    float *bmax = nullptr;           // DEV [padded queries of a chunk][bstride]: 128-row block maxima
+    int64_t tmax_floats = 0, bmax_floats = 0;
+    uint32_t *selb = nullptr;        // DEV [queries of a chunk][kp + 1]: selected blocks
+    int64_t selb_cap = 0;
+    int *okq = nullptr;              // DEV [kBigChunk] verification result per query, [4] failure count, [kBigChunk] failed queries
+    bool last_big = false;           // the last search went through the large-batch scan
+    bool bigq = true;                // IVR_SCAN_BIGQ=0 keeps every batch on the 64-query chunks (A/B switch, read at creation)
 };
 
 namespace {
@@ -756,6 +873,9 @@ int64_t tile_bytes(const ivr_index *x, int64_t rows) { return rows * (int64_t)x-
 
 int64_t tile16_bytes(const ivr_index *x, int64_t rows) { return (rows / 16) * (int64_t)x->pieces * 1024; }
 
+constexpr int kBigChunk = 1024;      // queries per launch chain of the large-batch scan
+constexpr int kBigMaxK = 128;        // beyond this k the chunks of 64 queries are used (candidate lists grow with k)
+
 int index_alloc(ivr_index *x, int64_t rows) {
     rows = ivr_round_up(std::max<int64_t>(rows, kGroupRows), kGroupRows);
     float *nd = nullptr;
@@ -763,8 +883,9 @@ int index_alloc(ivr_index *x, int64_t rows) {
     IVR_HIP(hipMemset(nd, 0, (size_t)tile_bytes(x, rows)));
     uint4 *nd16 = nullptr;
     if (x->scan16) {
-        IVR_HIP(hipMalloc(&nd16, (size_t)tile16_bytes(x, rows)));
-        IVR_HIP(hipMemset(nd16, 0, (size_t)tile16_bytes(x, rows)));
+        // padded to whole 256-row blocks: the large-batch scan streams blocks (rows past ntotal are masked, never out of bounds)
+        IVR_HIP(hipMalloc(&nd16, (size_t)tile16_bytes(x, ivr_round_up(rows, 256))));
+        IVR_HIP(hipMemset(nd16, 0, (size_t)tile16_bytes(x, ivr_round_up(rows, 256))));
     }
     if (x->data) {
         if (x->ntotal > 0) {
@@ -792,7 +913,9 @@ int launch_tile_rows(ivr_index *x, float *dst, const float *src, int64_t start, 
     // query tiles: the padding rows of the last tile are zero-filled by the kernel itself (no memset in front of it)
     hipLaunchKernelGGL(tile_rows_kernel, dim3(grid), dim3(256), 0, s, src, dst, start, n, x->d, x->dp4, normalize, nonfinite, start_dev,
                        x->scan16 ? (rows ? x->data16 : x->q16hi) : (uint4 *)nullptr, x->scan16 && !rows ? x->q16lo : (uint4 *)nullptr,
-                       x->scan16 && rows ? x->maxnorm : (unsigned int *)nullptr, rows ? (float *)nullptr : x->qnorm, rows ? 0 : 1);
+                       x->scan16 && rows ? x->maxnorm : (unsigned int *)nullptr, rows ? (float *)nullptr : x->qnorm, rows ? 0 : 1,
+                       x->pieces, x->scan16 && rows ? x->maxdelta : (unsigned int *)nullptr,
+                       x->scan16 && !rows ? x->qdelta : (float *)nullptr);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }
@@ -804,13 +927,20 @@ int pick_qt(int nq) { return nq <= 16 ? 1 : nq <= 32 ? 2 : nq <= 48 ? 3 : 4; }
 // groups re-scored exactly behind the bf16 candidate scan: k plus slack for what the approximate ranking may displace
 int fast_groups(int k) { return k + std::max(22, k); }
 
+// more than 64 queries: the tiled large-batch scan (search_scanq.hip) instead of chunks of 64 queries past the streamed index
+bool use_big(const ivr_index *x, int nq, int k) { return x->scan16 && x->bigq && nq > 64 && k <= kBigMaxK; }
+
 int reserve_search(ivr_index *x, int nq, int k) {
-    const int qtiles = (int)ivr_ceil_div(nq, 16);
+    const bool big = use_big(x, nq, k);
+    // the large-batch scan reads whole blocks of 256 queries: the tiled query buffers are padded (zero rows) to that
+    const int qtiles = (int)ivr_ceil_div(big ? ivr_round_up(nq, 256) : nq, 16);
     if (qtiles > x->qtiles_cap) {
         if (x->qtiles_cap) IVR_HIP(hipFree(x->qtiled));
         if (x->qnorm) IVR_HIP(hipFree(x->qnorm));
+        if (x->qdelta) IVR_HIP(hipFree(x->qdelta));
         x->qtiled = nullptr;
         x->qnorm = nullptr;
+        x->qdelta = nullptr;
         x->qtiles_cap = 0;
         const int want = std::max(qtiles, 4);
         IVR_HIP(hipMalloc(&x->qtiled, (size_t)want * 16 * x->dp * 4));
@@ -824,6 +954,8 @@ int reserve_search(ivr_index *x, int nq, int k) {
             IVR_HIP(hipMalloc(&x->q16lo, (size_t)want * x->pieces * 1024));
             IVR_HIP(hipMemset(x->q16hi, 0, (size_t)want * x->pieces * 1024));
             IVR_HIP(hipMemset(x->q16lo, 0, (size_t)want * x->pieces * 1024));
+            IVR_HIP(hipMalloc(&x->qdelta, (size_t)want * 16 * 4));
+            IVR_HIP(hipMemset(x->qdelta, 0, (size_t)want * 16 * 4));
         }
         x->qtiles_cap = want;
     }
@@ -836,7 +968,8 @@ int reserve_search(ivr_index *x, int nq, int k) {
         IVR_HIP(hipMalloc(&x->gmax, (size_t)need_gmax * 4));
         x->gmax_floats = need_gmax;
     }
-    const int64_t need_sel = (int64_t)std::min(nq, 64) * (x->scan16 ? fast_groups(k) + 1 : k);   // per scan chunk
+    const int chunk_q = std::min(nq, big ? kBigChunk : 64);
+    const int64_t need_sel = (int64_t)chunk_q * (x->scan16 ? fast_groups(k) + 1 : k);   // per scan chunk
     if (need_sel > x->sel_cap) {
         if (x->sel) IVR_HIP(hipFree(x->sel));
         if (x->cand) IVR_HIP(hipFree(x->cand));
@@ -846,6 +979,37 @@ int reserve_search(ivr_index *x, int nq, int k) {
         IVR_HIP(hipMalloc(&x->sel, (size_t)need_sel * 4));
         IVR_HIP(hipMalloc(&x->cand, (size_t)need_sel * kGroupRows * 8));
         x->sel_cap = need_sel;
+    }
+    if (big) {
+        const int qpad = (int)ivr_round_up(chunk_q, 256);
+        const int64_t cap256 = ivr_round_up(x->cap, 256);
+        const int64_t need_t = (int64_t)qpad * ivr_round_up(cap256 / 16, 64), need_b = (int64_t)qpad * ivr_round_up(cap256 / 128, 64);
+        if (need_t > x->tmax_floats) {
+            if (x->tmax) IVR_HIP(hipFree(x->tmax));
+            x->tmax = nullptr;
+            x->tmax_floats = 0;
+            IVR_HIP(hipMalloc(&x->tmax, (size_t)need_t * 4));
+            x->tmax_floats = need_t;
+        }
+        if (need_b > x->bmax_floats) {
+            if (x->bmax) IVR_HIP(hipFree(x->bmax));
+            x->bmax = nullptr;
+            x->bmax_floats = 0;
+            IVR_HIP(hipMalloc(&x->bmax, (size_t)need_b * 4));
+            x->bmax_floats = need_b;
+        }
+        const int64_t need_selb = (int64_t)chunk_q * (fast_groups(k) + 1);
+        if (need_selb > x->selb_cap) {
+            if (x->selb) IVR_HIP(hipFree(x->selb));
+            x->selb = nullptr;
+            x->selb_cap = 0;
+            IVR_HIP(hipMalloc(&x->selb, (size_t)need_selb * 4));
+            x->selb_cap = need_selb;
+        }
+        if (!x->okq) {
+            IVR_HIP(hipMalloc(&x->okq, (size_t)(2 * kBigChunk + 4) * sizeof(int)));
+            IVR_HIP(hipMemset(x->okq, 0, (size_t)(2 * kBigChunk + 4) * sizeof(int)));
+        }
     }
     return IVR_OK;
 }
@@ -883,6 +1047,128 @@ void launch_scan16(ivr_index *x, int64_t tile0, int64_t ngroups, int64_t mstride
                        x->q16lo + tile0 * x->pieces * 64, x->pieces, ngroups, x->ntotal, x->gmax, mstride);
 }
 
+template <int QT>
+void launch_scan_list(ivr_index *x, const float *qt, int64_t ngroups, int64_t mstride, float *gmax, const int *nlist, const int *list,
+                      hipStream_t s) {
+    const size_t lds = (size_t)QT * 16 * x->dp * 4;
+    const int threads = 512, nw = threads / 64;
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(lds, 1)));
+    int64_t grid = std::max<int64_t>(1, std::min<int64_t>(ivr_ceil_div(ngroups, nw), (int64_t)x->ctx->cu_count * per_cu));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scan_groupmax_list_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    IvrProf prof("scan_groupmax_list", s, 0.0, true);      // normally nothing is listed and every workgroup exits at once
+    hipLaunchKernelGGL(scan_groupmax_list_kernel<QT>, dim3((unsigned)grid), dim3(threads), lds, s, x->data, qt, x->dp4, ngroups, x->ntotal,
+                       gmax, mstride, nlist, list);
+}
+
+// One chunk (<= kBigChunk queries, already tiled at tile q0 / 16) of a large batch:
+//   scanq (index read once) -> top kp+1 blocks of 128 rows per query -> top kp+1 tiles of 16 rows among those blocks' tiles (the kp+1
+//   best tiles always lie inside the kp+1 best blocks: the argument of DESIGN.md section 4 with tiles for rows) -> exact float32
+//   re-score of kp tiles -> final selection, which also verifies the approximate ranking per query and lists the queries that
+//   fail -> list-driven exact pass (four launches that exit at once when the list is empty; no host round trip).
+int search_big(ivr_index *x, int q0, int nqc, int k, int64_t id_base, float *D, int64_t *I, hipStream_t s) {
+    const int kp = fast_groups(k), ksel2 = kp + 1;
+    const int qpad = (int)ivr_round_up(nqc, 256);
+    const int64_t cap256 = ivr_round_up(x->cap, 256);
+    const int64_t tstride = ivr_round_up(cap256 / 16, 64), bstride = ivr_round_up(cap256 / 128, 64);
+    const int64_t nblk128 = ivr_ceil_div(x->ntotal, 128), ntiles = ivr_ceil_div(x->ntotal, 16);
+    const int64_t ngroups = ivr_ceil_div(x->ntotal, kGroupRows), mstride = ivr_round_up(x->cap / kGroupRows, 64);
+    const float *qtile = x->qtiled + (int64_t)(q0 / 16) * 16 * x->dp;
+    int *ok = x->okq, *nfail = x->okq + kBigChunk, *flist = x->okq + kBigChunk + 4;
+    ScanQArgs a;
+    a.data16 = x->data16;
+    a.q16 = x->q16hi + (int64_t)(q0 / 16) * x->pieces * 64;
+    a.pieces = x->pieces;
+    a.qblocks = qpad / 256;
+    a.ntotal = x->ntotal;
+    a.nblocks = ivr_ceil_div(x->ntotal, 256);
+    a.tmax = x->tmax;
+    a.tstride = tstride;
+    a.bmax = x->bmax;
+    a.bstride = bstride;
+    int rc = ivr_launch_scanq(x->ctx, a, s);
+    if (rc != IVR_OK) return rc;
+    {
+        SrcGroupMax sb{x->bmax, bstride, nblk128};
+        IvrProf prof("select_blocks", s, (double)nqc * nblk128 * 4, true);
+        hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(sel_threads(nblk128)), 0, s, sb, 0, ksel2, (int64_t)0,
+                           x->selb, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr, (const int *)nullptr, VerifyArgs(), nfail,
+                           ListArgs());
+        IVR_LAUNCH_CHECK();
+    }
+    {
+        SrcTilesOf st{x->tmax, tstride, x->selb, ksel2, ntiles, (int64_t)ksel2 * 8};
+        IvrProf prof("select_tiles", s, (double)nqc * ksel2 * 8 * 4, true);
+        hipLaunchKernelGGL((select_topk_kernel<SrcTilesOf, OUT_GROUPS>), dim3(nqc), dim3(sel_threads((int64_t)ksel2 * 8)), 0, s, st, 0, ksel2,
+                           (int64_t)0, x->sel, (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr, (const int *)nullptr,
+                           VerifyArgs(), (int *)nullptr, ListArgs());
+        IVR_LAUNCH_CHECK();
+    }
+    {
+        const int64_t waves = (int64_t)nqc * kp;
+        IvrProf prof("rescore_tiles", s, (double)waves * 16 * x->dp * 4, true);
+        hipLaunchKernelGGL(rescore_groups_kernel<true>, dim3((unsigned)ivr_ceil_div(waves, 4)), dim3(256), 0, s, x->data, qtile, x->dp4, x->ntotal,
+                           x->sel, ksel2, kp, nqc, x->cand, (const int *)nullptr, ListArgs());
+        IVR_LAUNCH_CHECK();
+    }
+    {
+        SrcKeys sk{x->cand, (int64_t)kp * 16};
+        VerifyArgs vf;
+        vf.gmax = x->tmax;
+        vf.mstride = tstride;
+        vf.sel = x->sel;
+        vf.ksel2 = ksel2;
+        vf.kp = kp;
+        vf.qnorm = x->qnorm + q0;
+        vf.maxnorm_bits = x->maxnorm;
+        vf.ok = ok;
+        vf.qdelta = x->qdelta + q0;
+        vf.maxdelta_bits = x->maxdelta;
+        vf.acc_eps = (float)x->dp * 1.2e-7f;
+        vf.fail_count = nfail;
+        vf.fail_list = flist;
+        IvrProf prof("select_final", s, (double)nqc * kp * 16 * 8, true);
+        hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(sel_threads((int64_t)kp * 16)), 0, s, sk, 0, k, id_base,
+                           (uint32_t *)nullptr, D + (int64_t)q0 * k, I + (int64_t)q0 * k, (const int64_t *)nullptr, (const int *)nullptr, vf,
+                           (int *)nullptr, ListArgs());
+        IVR_LAUNCH_CHECK();
+    }
+    // exact pass over the listed queries; its group maxima reuse the tile-maxima buffer (read for the last time just above)
+    const ListArgs la{nfail, flist};
+    float *gmax = x->tmax;
+    const int qt_max = (int)std::max<int64_t>(1, std::min<int64_t>(4, (128 * 1024) / ((int64_t)16 * x->dp * 4)));
+    switch (qt_max) {
+        case 1: launch_scan_list<1>(x, qtile, ngroups, mstride, gmax, nfail, flist, s); break;
+        case 2: launch_scan_list<2>(x, qtile, ngroups, mstride, gmax, nfail, flist, s); break;
+        case 3: launch_scan_list<3>(x, qtile, ngroups, mstride, gmax, nfail, flist, s); break;
+        default: launch_scan_list<4>(x, qtile, ngroups, mstride, gmax, nfail, flist, s); break;
+    }
+    IVR_LAUNCH_CHECK();
+    {
+        SrcGroupMax sg{gmax, mstride, ngroups};
+        IvrProf prof("select_groups", s, 0.0, true);
+        hipLaunchKernelGGL((select_topk_kernel<SrcGroupMax, OUT_GROUPS>), dim3(nqc), dim3(sel_threads(ngroups)), 0, s, sg, 0, k, (int64_t)0, x->sel,
+                           (float *)nullptr, (int64_t *)nullptr, (const int64_t *)nullptr, (const int *)nullptr, VerifyArgs(), (int *)nullptr, la);
+        IVR_LAUNCH_CHECK();
+    }
+    {
+        const int64_t waves = (int64_t)nqc * k;
+        IvrProf prof("rescore_groups", s, 0.0, true);
+        hipLaunchKernelGGL(rescore_groups_kernel<false>, dim3((unsigned)waves), dim3(256), 0, s, x->data, qtile, x->dp4, x->ntotal, x->sel, k, k, nqc,
+                           x->cand, (const int *)nullptr, la);
+        IVR_LAUNCH_CHECK();
+    }
+    {
+        SrcKeys sk{x->cand, (int64_t)k * kGroupRows};
+        IvrProf prof("select_final", s, 0.0, true);
+        hipLaunchKernelGGL((select_topk_kernel<SrcKeys, OUT_DI>), dim3(nqc), dim3(sel_threads((int64_t)k * kGroupRows)), 0, s, sk, 0, k, id_base,
+                           (uint32_t *)nullptr, D + (int64_t)q0 * k, I + (int64_t)q0 * k, (const int64_t *)nullptr, (const int *)nullptr, VerifyArgs(),
+                           (int *)nullptr, la);
+        IVR_LAUNCH_CHECK();
+    }
+    return IVR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -902,12 +1188,18 @@ int ivr_index_create(ivr_ctx *ctx, int d, int64_t capacity_rows, ivr_index **out
     {
         const char *e = getenv("IVR_SCAN_BF16");       // A/B switch, read when the index is created
         x->scan16 = !(e && e[0] == '0');   // LDS per 16-query tile (hi + lo) = 64 dp bytes, the same as the float32 scan's
+        const char *b = getenv("IVR_SCAN_BIGQ");
+        x->bigq = !(b && b[0] == '0');
     }
+    // an even number of pieces per tile: the large-batch scan steps K by two pieces; an odd tail piece stays all zero on both sides
+    x->pieces = (int)ivr_round_up(x->pieces, 2);
     if (x->scan16) {
         IVR_HIP(hipMalloc(&x->maxnorm, 4));
         IVR_HIP(hipMemset(x->maxnorm, 0, 4));
         IVR_HIP(hipMalloc(&x->okflag, 68 * sizeof(int)));
         IVR_HIP(hipMemset(x->okflag, 0, 68 * sizeof(int)));
+        IVR_HIP(hipMalloc(&x->maxdelta, 4));
+        IVR_HIP(hipMemset(x->maxdelta, 0, 4));
     }
     int rc = index_alloc(x, capacity_rows);
     if (rc != IVR_OK) {
@@ -926,7 +1218,8 @@ int ivr_index_destroy(ivr_index *x) {
     if (x->gmax) (void)hipFree(x->gmax);
     if (x->sel) (void)hipFree(x->sel);
     if (x->cand) (void)hipFree(x->cand);
-    for (void *p : {(void *)x->data16, (void *)x->q16hi, (void *)x->q16lo, (void *)x->maxnorm, (void *)x->okflag})
+    for (void *p : {(void *)x->data16, (void *)x->q16hi, (void *)x->q16lo, (void *)x->maxnorm, (void *)x->okflag, (void *)x->maxdelta,
+                    (void *)x->qdelta, (void *)x->tmax, (void *)x->bmax, (void *)x->selb, (void *)x->okq})
         if (p) (void)hipFree(p);
     delete x;
     return IVR_OK;
@@ -938,8 +1231,9 @@ int ivr_index_reset(ivr_index *x) {
     IVR_HIP(hipSetDevice(x->ctx->device));
     IVR_HIP(hipMemset(x->data, 0, (size_t)tile_bytes(x, x->cap)));
     if (x->scan16) {
-        IVR_HIP(hipMemset(x->data16, 0, (size_t)tile16_bytes(x, x->cap)));
+        IVR_HIP(hipMemset(x->data16, 0, (size_t)tile16_bytes(x, ivr_round_up(x->cap, 256))));
         IVR_HIP(hipMemset(x->maxnorm, 0, 4));
+        IVR_HIP(hipMemset(x->maxdelta, 0, 4));
     }
     x->ntotal = 0;
     return IVR_OK;
@@ -1039,6 +1333,18 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
     // range.  Its result is verified per query on the device; failures are redone by the exact pass below (tile_flag / skip).
     const int kp = fast_groups(k);
     const bool fast = x->scan16 && ngroups >= 4 * (int64_t)(kp + 1) && kp + 1 <= IVR_MAX_K;
+    x->last_big = false;
+    if (fast && use_big(x, nq, k)) {
+        // large batch: the index is read once per kBigChunk queries instead of once per 64
+        for (int q0 = 0; q0 < nq; q0 += kBigChunk) {
+            const int nqc = std::min(kBigChunk, nq - q0);
+            rc = search_big(x, q0, nqc, k, id_base, D, I, s);
+            if (rc != IVR_OK) return rc;
+            x->last_nqc = nqc;
+        }
+        x->last_big = true;
+        return IVR_OK;
+    }
     // bf16 keeps 8 significant bits: |row - bf16(row)| <= 2^-8 |row| per element; the query's hi + lo leaves 2^-16; f32 accumulation
     const float rel_eps = (0.00390625f + 0.0000306f + (float)x->dp * 1.2e-7f) * 1.01f;
     int *ok = x->okflag, *tile_flag = x->okflag ? x->okflag + 64 : nullptr;
@@ -1063,8 +1369,8 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         // rescore reads query tile (q >> 4) relative to the chunk's first tile
         {
             IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4, true);
-            hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)waves), dim3(256), 0, s, x->data, qtile, x->dp4,
-                               x->ntotal, x->sel, ksel, ksel, nqc, x->cand, skip);
+            hipLaunchKernelGGL(rescore_groups_kernel<false>, dim3((unsigned)waves), dim3(256), 0, s, x->data, qtile, x->dp4,
+                               x->ntotal, x->sel, ksel, ksel, nqc, x->cand, skip, ListArgs());
         }
         IVR_LAUNCH_CHECK();
         SrcKeys sk{x->cand, (int64_t)ksel * kGroupRows};
@@ -1104,8 +1410,8 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         const int64_t waves = (int64_t)nqc * kp;
         {
             IvrProf prof("rescore_groups", s, (double)waves * kGroupRows * x->dp * 4, true);
-            hipLaunchKernelGGL(rescore_groups_kernel, dim3((unsigned)waves), dim3(256), 0, s, x->data, qtile, x->dp4,
-                               x->ntotal, x->sel, ksel2, kp, nqc, x->cand, (const int *)nullptr);
+            hipLaunchKernelGGL(rescore_groups_kernel<false>, dim3((unsigned)waves), dim3(256), 0, s, x->data, qtile, x->dp4,
+                               x->ntotal, x->sel, ksel2, kp, nqc, x->cand, (const int *)nullptr, ListArgs());
         }
         IVR_LAUNCH_CHECK();
         {
@@ -1142,6 +1448,10 @@ int ivr_index_scan_stats(ivr_index *x, int *out) {
     if (!x->scan16) return IVR_OK;
     IVR_HIP(hipSetDevice(x->ctx->device));
     IVR_HIP(hipDeviceSynchronize());
+    if (x->last_big) {       // large-batch scan: the length of the failure list of the last chunk
+        IVR_HIP(hipMemcpy(&out[1], x->okq + kBigChunk, sizeof(int), hipMemcpyDeviceToHost));
+        return IVR_OK;
+    }
     int ok[64];
     IVR_HIP(hipMemcpy(ok, x->okflag, sizeof(ok), hipMemcpyDeviceToHost));
     for (int i = 0; i < x->last_nqc; ++i) out[1] += ok[i] == 0;

@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, "/root/repo/intelligent-video-analysis-retrieval-system_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "intelligent-video-analysis-retrieval-system_amd"))
 import torch
 from ivr_amd import _ffi
 from ivr_amd.index import FlatIPIndex

@@ -22,7 +22,7 @@ last_print = t0
 while time.time() - t0 < budget:
     d = int(rng.choice([16, 48, 96, 128, 384, 512, 768, 1000]))
     N = int(rng.integers(20_000, 400_000))
-    nq = int(rng.choice([1, 3, 10, 16, 17, 64, 65, 130]))
+    nq = int(rng.choice([1, 3, 10, 16, 17, 64, 65, 130, 300, 1100]))
     k = int(rng.choice([1, 5, 10, 50, 100]))
     kind = rng.choice(["gauss", "clustered", "dups", "scaled", "sparse", "zeros"])
     g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
