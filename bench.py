@@ -9,6 +9,8 @@ A "step" is one pass of the whole path over one batch, inputs already resident i
     [N > 1: one RCCL all-gather of the per-shard candidates + merge]
 value = frames embedded per second by the whole job (every frame also pays its share of the search);
 pairs_per_s = query x index-row cosines per second of the search part alone (HIP events), also reported.
+extra.configs2_sharded (every N): BASELINE configs[2] as a strong-scaling leg - 10M rows x 512-d split over the N ranks, 1,000
+replicated queries, local exact top-10, one all-gather of (score, id) + merge: search_ms, allgather_merge_ms, pairs_per_s.
 
 python bench.py --gpus N --steps K --warmup W
 N > 1: one rank per GPU.  Started from a plain shell the script launches `python -m torch.distributed.run --nnodes=1
@@ -76,7 +78,30 @@ def cpu_baseline(cfg, weights, index_rows, queries, k, budget_s=25.0):
         if time.perf_counter() - t1 > 5.0 or reps >= 20:
             break
     t_search = (time.perf_counter() - t1) / reps
-    return {"value": done / t_embed, "unit": "frames/s", "cores": cores, "kind": "port",
+    # per-core figure: 64 of the same frames and the same 100k-row search on ONE thread
+    torch.set_num_threads(1)
+    t1 = time.perf_counter()
+    for i in range(0, 64, 32):
+        V.vision_forward(cfg, weights, P.preprocess(frames[i:i + 32], "identity", C.CLIP_MEAN, C.CLIP_STD))
+    t_embed1 = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    S.flat_ip_search(index_rows, queries, k)
+    t_search1 = time.perf_counter() - t1
+    torch.set_num_threads(cores)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": done / t_embed, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+            "logical_cpus": os.cpu_count(),
+            "one_thread": {"frames_per_s": 64 / t_embed1, "pairs_per_s": len(index_rows) * len(queries) / t_search1,
+                           "sample": f"64 frames through the fp32 oracle + one exact IP top-{k} of {len(queries)} queries over the "
+                                     f"{len(index_rows)}-row slice, torch.set_num_threads(1) (NumPy's BLAS keeps its own pool for the search)"},
             "sample": f"configs[0]{' exactly' if done == len(frames) else ' cut at the time budget'}: {done} of 1000 frames of 224x224 "
                       f"through the fp32 oracle {cfg.name} in batches of 32 ({t_embed:.1f} s), 10 queries top-10 over those "
                       f"{len(rows0)} rows ({t_s0 * 1e6:.0f} us per search); pairs/s from the exact IP top-{k} of {len(queries)} queries "
@@ -116,16 +141,16 @@ def side_configs(dev, weights_b32):
             for _ in range(2):
                 index.search_device(q, 10, normalize=True)
             ms = timed(lambda: index.search_device(q, 10, normalize=True), 5)
-            # parity at full size on a sample: 8 of the 1000 queries against the float64 oracle over the rows the device holds
+            # parity at full size on a sample: 64 of the 1000 queries against the float64 oracle over the rows the device holds
             from oracle import search_ref as S
             Dq, Iq = index.search_device(q, 10, normalize=True)
-            pick = np.arange(0, 1000, 125)
+            pick = np.arange(0, 1000, 16)[:64]
             Xh = index.reconstruct_n(0, 1_250_000)
             qn = S.normalize_rows_core(q[pick].cpu().numpy()).astype(np.float32)
             Dr, Ir = S.flat_ip_search(Xh, qn, 10, dtype=np.float64)
             out["configs2_one_shard"] = {"rows": 1_250_000, "queries": 1000, "k": 10, "search_ms": ms,
                                          "pairs_per_s": 1_250_000 * 1000 / (ms * 1e-3),
-                                         "ids_exact_on_sample_of_8_queries": bool(np.array_equal(Iq[pick].cpu().numpy(), Ir)),
+                                         "ids_exact_on_sample_of_64_queries": bool(np.array_equal(Iq[pick].cpu().numpy(), Ir)),
                                          "max_abs_score_err_on_sample": float(np.abs(Dq[pick].cpu().numpy() - Dr).max())}
             del Xh
     cfg = C.CLIP_VIT_B32
@@ -167,6 +192,74 @@ def side_configs(dev, weights_b32):
                    "tests/test_fp8_gpu.py, profiles/r02_fp8_error_budget.json")
     out["configs4_tower_vit_l14"] = l14
     return out
+
+
+def configs2_sharded(dev, rank, world, total_rows=10_000_000, nq=1000, k=10, reps=5):
+    """BASELINE configs[2] as a STRONG-scaling leg, run at every world size: a 10M-row x 512-d index row-sharded over the ranks
+    (10M / world rows each, Gaussian rows seeded per shard), a replicated 1,000-query batch, local exact top-10 with global ids, ONE
+    all-gather of the per-shard (score, id) candidates and the k-way merge on every rank (replaces the peer fan-out + concat + sort of
+    system.py:1715-1757 / :1744-1746).  Times are the MAX over ranks; pairs/s = 10M x 1000 / whole search."""
+    from ivr_amd.index import FlatIPIndex
+    from ivr_amd.sharded import ShardedIndex, shard_bounds
+    lo, hi = shard_bounds(total_rows, world)[rank]
+    n = hi - lo
+    index = FlatIPIndex(512, capacity=n, device=dev.index)
+    g = torch.Generator(device=dev).manual_seed(777 + rank)
+    for i in range(0, n, 250_000):
+        index.add(torch.randn((min(250_000, n - i), 512), generator=g, device=dev), normalize=True)
+    q = torch.from_numpy(np.random.default_rng(4242).standard_normal((nq, 512), dtype=np.float32)).to(dev)
+    index.reserve_search(nq, k)
+    sh = ShardedIndex(index, 512, merge="device")
+    sh.sync_counts()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        sync()
+        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e3, out
+
+    local_ms, _ = timed(lambda: index.search_device(q, k, normalize=True, id_base=sh.id_base))
+    total_ms, (D, I) = timed(lambda: sh.search(q, k, normalize=True))
+    # size-independent checks on the merged result: scores descend, ids are unique per query and inside the global range, every
+    # rank holds the same answer; and this rank's own rows come back first when they are the queries
+    ok = bool((D[:, :-1] >= D[:, 1:]).all()) and bool(((I >= 0) & (I < total_rows)).all())
+    ok = ok and all(len(set(r)) == k for r in I[:16].cpu().tolist())
+    mine = torch.from_numpy(index.reconstruct_n(0, 4)).to(dev)
+    if world > 1:
+        probe = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(probe, mine)
+        probe = torch.cat(probe)
+        sig = I.sum().reshape(1).clone()
+        sigs = [torch.empty_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        ok = ok and all(int(x) == int(sigs[0]) for x in sigs)
+    else:
+        probe = mine
+    Dp, Ip = sh.search(probe, 1, normalize=False)
+    bases = [b for b, _ in shard_bounds(total_rows, world)]
+    want = [b + j for b in bases for j in range(4)]
+    ok = ok and Ip.flatten().cpu().tolist() == want and float((Dp - 1).abs().max()) < 1e-5
+    _, redone = index.scan_stats()
+    res = {"rows_total": total_rows, "rows_per_rank": n, "ranks": world, "queries": nq, "k": k, "search_ms": local_ms,
+           "allgather_merge_ms": max(0.0, total_ms - local_ms), "total_ms": total_ms, "pairs_per_s": total_rows * nq / (total_ms * 1e-3),
+           "scaling": "strong", "allgather_bytes_per_rank": nq * k * 12, "checks_ok": bool(ok),
+           "queries_redone_by_the_exact_pass_on_rank0": int(redone),
+           "note": "local search timed alone, then search + all-gather + merge; both = max over ranks of the mean of %d repeats" % reps}
+    del index, sh
+    torch.cuda.empty_cache()
+    return res
 
 
 def _free_port():
@@ -375,6 +468,9 @@ def main():
     search_kernels_us = {n: v["ms"] / v["launches"] * 1e3 for n, v in sorted(_ffi.profile_read(local_rank).items())}
     if world > 1:
         dist.barrier()
+    c2 = None
+    if headline and not args.no_extra:
+        c2 = configs2_sharded(dev, rank, world)
 
     if rank == 0:
         frames_total = B * args.steps * world
@@ -448,6 +544,14 @@ def main():
         out["recall_at_10"] = float(np.mean([len(set(Il[q]) & set(Ir[q])) / k for q in range(Q)]))
         out["ids_exact"] = bool(np.array_equal(Il, Ir))
         out["max_abs_score_err"] = float(np.abs(Dl - Dr).max())
+        # SURVEY.md section 8 hard part 2: recall with and without the re-rank.  "Without" = the top-k of the bf16 candidate
+        # ranking alone (<bf16(row), q> in f32, emulated here with torch on the same rows; the library never reports these scores)
+        Xd = torch.from_numpy(Xh).to(dev)
+        approx = torch.from_numpy(qn).to(dev) @ Xd.to(torch.bfloat16).to(torch.float32).T
+        Ia = torch.topk(approx, k, dim=1).indices.cpu().numpy()
+        out["recall_at_10_candidates_only"] = float(np.mean([len(set(Ia[q]) & set(Ir[q])) / k for q in range(Q)]))
+        out["ids_exact_candidates_only"] = bool(np.array_equal(Ia, Ir))
+        del Xd, approx
         for key in ("roofline", "roofline_search", "roofline_preprocess"):
             if out.get(key):
                 out[key]["traffic_source"] = (f"profiles/{PMC_FILE} (rocprofv3 --pmc passes of this same command, tools/pmc_aggregate.py; "
@@ -459,6 +563,8 @@ def main():
             del frame_tiles, patches, emb, index, sharded, towers, tower, Xh
             torch.cuda.empty_cache()
             out["extra"] = side_configs(dev, weights)
+        if c2 is not None:
+            out.setdefault("extra", {})["configs2_sharded"] = c2
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -88,11 +88,16 @@ class ShardedIndex:
     def search(self, q, k, normalize=False):
         """q [nq,d] replicated on every rank -> (D [nq,k], I [nq,k] global ids), identical on every rank."""
         D, I = self.local.search_device(q, k, normalize=normalize, id_base=self.id_base)
+        return self.exchange(D, I)
+
+    def exchange(self, D, I):
+        """The single exchange step of the path: this rank's candidates (D [nq,k] scores, I [nq,k] GLOBAL ids, unused slots -1)
+        -> the merged top-k over all shards, identical on every rank.  ONE all-gather of nq*k*12 bytes per rank - (score f32,
+        id i64) packed as three int32 words per candidate - then the k-way merge.  Enqueued on the current stream (RCCL work is
+        stream-ordered), so it can follow a replayed HIP graph that produced D and I (streaming.StreamingSession)."""
         if self.world == 1:
             return D, I
-        nq = D.shape[0]
-        # the single exchange step of the path: ONE all-gather of nq*k*12 bytes per rank - (score f32, id i64) packed as
-        # three int32 words per candidate - so every rank holds every shard's candidates
+        nq, k = D.shape
         cand = torch.empty((nq, k, 3), dtype=torch.int32, device=D.device)
         cand[..., 0] = D.contiguous().view(torch.int32)
         cand[..., 1:] = I.contiguous().view(torch.int32).view(nq, k, 2)

@@ -4,7 +4,14 @@ captured once as a HIP graph and replayed per step.
 
 Everything the step touches is a static device buffer (frames in, (D, I) out) and the ring cursor lives in HBM, so
 the captured graph contains no host-dependent argument.  The reference has no streaming mode; this is the batched,
-graph-launched form of its per-frame loop (`video_frame_filter.py:53-85`) feeding `search_vectors`.
+graph-launched form of its per-frame loop (`video_frame_filter.py:53-85`) feeding `search_vectors` (`unified_index.py:480`).
+
+Several GPUs: every feed is pinned to one GPU.  Rank r embeds its own feeds' frames, overwrites its OWN ring
+(the rolling window is row-sharded: rank r holds global ids [r*W, (r+1)*W), W = window rows per rank), searches it with the
+replicated query batch, and the step ends with the same single all-gather + merge as the static sharded search
+(`sharded.ShardedIndex.exchange`).  The captured graph holds this rank's kernels only; the collective and the merge kernel are
+issued on the same stream right after the replay - RCCL calls are stream-ordered but are not captured here (a captured collective
+pins communicator state into the graph; keeping it outside lets one graph serve any world size and the gloo rehearsal).
 """
 import torch
 
@@ -14,12 +21,18 @@ from .preprocess import preprocess_frames
 
 class StreamingSession:
     def __init__(self, tower, index, frames_per_step, height, width, queries, k=10, mode="stretch", bgr=True,
-                 mean=CLIP_MEAN, std=CLIP_STD, normalize_queries=True, use_graph=True):
+                 mean=CLIP_MEAN, std=CLIP_STD, normalize_queries=True, use_graph=True, sharded=None, preprocess=preprocess_frames):
+        """sharded: a `sharded.ShardedIndex` wrapping `index` (this rank's ring) - the step then returns the merged result over
+        every rank's ring, global ids = sharded.id_base + ring position.  preprocess: the resize + normalise entry point (the HIP
+        kernel; the world_size-2 CPU test plugs in a stand-in together with tower / index doubles)."""
         if index.ntotal % frames_per_step:
             raise ValueError("the rolling index size must be a multiple of frames_per_step")
         if frames_per_step > tower.max_batch:
             raise ValueError("frames_per_step exceeds the tower's max_batch")
+        if sharded is not None and sharded.local is not index:
+            raise ValueError("sharded must wrap this session's own index")
         self.tower, self.index, self.n = tower, index, int(frames_per_step)
+        self.sharded, self._preprocess = sharded, preprocess
         dev = tower.device
         cfg = tower.cfg
         self.mode, self.bgr, self.mean, self.std, self.k = mode, bgr, mean, std, int(k)
@@ -53,11 +66,12 @@ class StreamingSession:
 
     def _enqueue(self):
         cfg = self.tower.cfg
-        preprocess_frames(self.frames, self.mode, self.mean, self.std, bgr=self.bgr, size=cfg.image, patch=cfg.patch,
-                          out_dtype=self.tower.act_dtype, out=self.patches)
+        self._preprocess(self.frames, self.mode, self.mean, self.std, bgr=self.bgr, size=cfg.image, patch=cfg.patch,
+                         out_dtype=self.tower.act_dtype, out=self.patches)
         self.tower.encode_patches(self.patches, self.n, normalize=True, out=self.emb)
         self.index.write_ring(self.emb, self.cursor)
-        self.index.search_device(self.queries, self.k, normalize=self.normalize_queries, out=(self.D, self.I))
+        self.index.search_device(self.queries, self.k, normalize=self.normalize_queries, out=(self.D, self.I),
+                                 id_base=self.sharded.id_base if self.sharded is not None else 0)
 
     def step(self, frames=None):
         """frames: uint8 [n,h,w,3] (CUDA or pinned host) for this step, or None to reuse the buffer.  Returns (D, I)
@@ -68,4 +82,7 @@ class StreamingSession:
             self.graph.replay()
         else:
             self._enqueue()
+        if self.sharded is not None and self.sharded.world > 1:
+            # the one exchange step: all-gather of every rank's (score, global id) candidates + merge, on the current stream
+            return self.sharded.exchange(self.D, self.I)
         return self.D, self.I
