@@ -1954,16 +1954,55 @@ int launch_gemm_e(int epi, const GemmArgs &g, hipStream_t s) {
 
 }  // namespace
 
+// The kernels address the row operand through one buffer resource with 32-bit offsets (2 GiB reach).  Row panels are independent,
+// so a taller operand is run as consecutive slabs of whole 256-row tiles (EPI_PATCH: of whole 256-image groups, its epilogue maps
+// rows to images), each with the base pointers advanced: ViT-B/32 from ~6.8 k frames per call, ViT-L/14 from ~1 k.
+static int64_t gemm_slab_rows(int64_t row_bytes, int64_t quantum) {
+    const int64_t most = (int64_t)0x7ffffff0 / std::max<int64_t>(row_bytes, 1);
+    return std::max<int64_t>(quantum, most / quantum * quantum);
+}
+
+template <typename Launch>
+static int gemm_in_slabs(const GemmArgs &g, int epi, int64_t in_elem, int64_t out_elem, Launch launch) {
+    int64_t quantum = epi == EPI_PATCH ? (int64_t)256 * g.G2 : 256;
+    if (g.skip_mod) {                  // rows r % skip_mod == 0 are skipped by the epilogue: slabs must start on such a row
+        int64_t a = quantum, b = g.skip_mod;
+        while (b) {
+            const int64_t t = a % b;
+            a = b;
+            b = t;
+        }
+        quantum = quantum / a * g.skip_mod;
+    }
+    const int64_t slab = gemm_slab_rows((int64_t)g.lda * in_elem, quantum);
+    IVR_REQUIRE(slab * g.lda * in_elem < 0x7fffffff, "gemm: a single slab of %lld rows x lda=%d exceeds the 2 GiB reach of the buffer offsets",
+                (long long)slab, g.lda);
+    for (int64_t m0 = 0; m0 < g.M; m0 += slab) {
+        GemmArgs ga = g;
+        ga.M = (int)std::min<int64_t>(slab, g.M - m0);
+        ga.A = reinterpret_cast<const char *>(g.A) + m0 * g.lda * in_elem;
+        if (epi == EPI_PATCH) {
+            if (g.resid) ga.resid = g.resid + (m0 / g.G2) * (int64_t)g.T * g.ldr;      // m0 is a whole number of images
+        } else {
+            if (g.out) ga.out = reinterpret_cast<char *>(g.out) + m0 * g.ldo * out_elem;
+            if (g.resid) ga.resid = g.resid + m0 * g.ldr;
+        }
+        if (int rc = launch(ga)) return rc;
+    }
+    return IVR_OK;
+}
+
 int ivr_launch_gemm(bool f32, int epi, const GemmArgs &g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return IVR_OK;
     const int epr = f32 ? 32 : 64;
     IVR_REQUIRE(g.K > 0 && g.K % epr == 0, "gemm: K=%d must be a multiple of %d", g.K, epr);
     IVR_REQUIRE(g.N % 4 == 0, "gemm: N=%d must be a multiple of 4", g.N);
     const int64_t es = f32 ? 4 : 2;
-    IVR_REQUIRE((int64_t)g.M * g.lda * es < 0x7fffffff && (int64_t)g.N * g.ldw * es < 0x7fffffff,
-                "gemm: an operand exceeds the 2 GiB reach of the 32-bit buffer offsets (M=%d lda=%d N=%d ldw=%d): use a smaller batch",
-                g.M, g.lda, g.N, g.ldw);
-    return f32 ? launch_gemm_e<float>(epi, g, s) : launch_gemm_e<unsigned short>(epi, g, s);
+    IVR_REQUIRE((int64_t)g.N * g.ldw * es < 0x7fffffff, "gemm: the weight operand exceeds the 2 GiB reach of the 32-bit buffer offsets (N=%d ldw=%d)",
+                g.N, g.ldw);
+    return gemm_in_slabs(g, epi, es, epi == EPI_F32 ? 4 : es, [&](const GemmArgs &ga) {
+        return f32 ? launch_gemm_e<float>(epi, ga, s) : launch_gemm_e<unsigned short>(epi, ga, s);
+    });
 }
 
 namespace {
@@ -1994,7 +2033,10 @@ int ivr_launch_gemm_fp8(int epi, const GemmArgs &g, hipStream_t s) {
     IVR_REQUIRE(g.K >= 128 && g.K % 128 == 0 && g.lda % 16 == 0 && g.ldw % 16 == 0, "fp8 gemm: K=%d lda=%d ldw=%d (K %% 128, ld %% 16)", g.K,
                 g.lda, g.ldw);
     IVR_REQUIRE(g.N % 64 == 0, "fp8 gemm: N=%d must be a multiple of 64", g.N);
-    IVR_REQUIRE((int64_t)g.M * g.lda < 0x7fffffff && (int64_t)g.N * g.ldw < 0x7fffffff, "fp8 gemm: operand beyond 2 GiB");
+    IVR_REQUIRE((int64_t)g.N * g.ldw < 0x7fffffff, "fp8 gemm: weight operand beyond 2 GiB");
+    if ((int64_t)g.M * g.lda >= 0x7fffffff) {        // tall row operand: whole 256-row slabs, see gemm_in_slabs
+        return gemm_in_slabs(g, epi, 1, g.out8 ? 1 : 2, [&](const GemmArgs &ga) { return ivr_launch_gemm_fp8(epi, ga, s); });
+    }
     const auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
     IVR_REQUIRE(al16(g.A) && al16(g.W) && al16(g.bias) && al16(g.colscale), "fp8 gemm: operands must be 16-byte aligned");
     if (epi == EPI_RESID) {

@@ -5,13 +5,18 @@ Stands in for the HuggingFace modules the reference calls at `core.py:1619`
 `video_frame_filter.py:31` (`ViTModel`).  Weights are the float32 master dict of
 `ivr_amd.weights` (synthetic or converted from an HF state dict); GEMM operands are
 cast to bf16 at upload unless `compute="f32"` (verification mode).  The e4m3 modes (BASELINE config 5) quantise
-linear sites of every block to e4m3 with one scale per output channel:
-  compute="fp8"      the MLP sites (fc1, fc2 = two thirds of the FLOPs) in e4m3, the token-0 rows of those sites on a bf16
-                     side path: the assignment that keeps 1 - cos(embedding, f32 embedding) <= 1e-3
-  compute="fp8_all"  all four sites (qkv, attn-out, fc1, fc2) in e4m3: fastest, 1 - cos ~ 4e-3 (3 mantissa bits)
-  compute="fp8_strict"  as "fp8" but only in the last third of the blocks (the early blocks' error passes through every later
-                     attention): the assignment that keeps |score - f32 score| <= 1e-3 against unrelated (text) queries too
+linear sites to e4m3 with one scale per output channel; the names say what each one holds:
+  compute="fp8"      THE assignment that meets the north-star bound, |score - f32 score| <= 1e-3 against image AND unrelated (text)
+                     queries: the MLP sites (fc1, fc2) in e4m3 in the last third of the blocks only (the early blocks' error passes
+                     through every later attention), their token-0 rows on a bf16 side path.  ("fp8_strict" is the old name, kept.)
+  compute="fp8_mlp"  fc1 + fc2 in e4m3 in EVERY block, token-0 rows bf16: 1 - cos(embedding, f32 embedding) <= 1e-3, image-query
+                     scores inside 1e-3, text-query scores up to ~2e-3 - faster, outside the score bound
+  compute="fp8_all"  all four sites (qkv, attn-out, fc1, fc2) in e4m3 in every block: fastest, 1 - cos ~ 4e-3 (3 mantissa bits)
   fp8_sites=(...), fp8_cls_bf16=..., fp8_first_layer=...  explicit assignment (tools/fp8_error_budget.py)
+Every bound above was established on RANDOM-INIT weights (make_weights(); the HF goldens are random-init too): no trained checkpoint
+is reachable offline.  Activations are cast to e4m3 at unit scale (saturation at 448, precision floor 2^-9), which is what the
+outlier stress test of tests/test_fp8_gpu.py exercises: trained CLIP towers have outlier channels, so re-run tools/fp8_error_budget.py
+on the real checkpoint (model_path= directory) before trusting a preset with it.
 """
 import ctypes as C
 
@@ -22,6 +27,8 @@ from . import _ffi
 from .config import TowerConfig
 from .preprocess import preprocess_frames
 
+FP8_PRESETS = ("fp8", "fp8_strict", "fp8_mlp", "fp8_all")
+
 
 class Tower:
     def __init__(self, cfg: TowerConfig, weights, max_batch=256, compute="bf16", device=None, fp8_sites=None, fp8_cls_bf16=None,
@@ -30,13 +37,13 @@ class Tower:
         self.cfg = cfg
         self.compute = compute
         sites, cls, first = 0, 0, 0
-        if compute in ("fp8", "fp8_all", "fp8_strict"):
+        if compute in FP8_PRESETS:
             if fp8_sites is None:
                 fp8_sites = ("qkv", "o", "fc1", "fc2") if compute == "fp8_all" else ("fc1", "fc2")
             if fp8_cls_bf16 is None:
                 fp8_cls_bf16 = compute != "fp8_all"
             if fp8_first_layer is None:
-                fp8_first_layer = (2 * cfg.layers) // 3 if compute == "fp8_strict" else 0
+                fp8_first_layer = (2 * cfg.layers) // 3 if compute in ("fp8", "fp8_strict") else 0
             first = int(fp8_first_layer)
             if not 0 <= first < cfg.layers:
                 raise ValueError(f"fp8_first_layer={first} outside [0,{cfg.layers})")
@@ -45,7 +52,7 @@ class Tower:
                 raise ValueError("fp8_sites is empty: use compute='bf16'")
             cls = int(bool(fp8_cls_bf16))
         elif fp8_sites is not None or fp8_cls_bf16 is not None or fp8_first_layer is not None:
-            raise ValueError("fp8_sites / fp8_cls_bf16 / fp8_first_layer only apply to compute='fp8' / 'fp8_all' / 'fp8_strict'")
+            raise ValueError("fp8_sites / fp8_cls_bf16 / fp8_first_layer only apply to compute='fp8' / 'fp8_mlp' / 'fp8_all'")
         self.fp8_sites, self.fp8_cls_bf16, self.fp8_first_layer = sites, cls, first
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
         self.max_batch = int(max_batch)
@@ -55,7 +62,7 @@ class Tower:
                            mlp=cfg.mlp, tokens=cfg.tokens, out_dim=cfg.out_dim, act=cfg.act, pool=cfg.pool,
                            image=cfg.image, patch=cfg.patch, pre_ln=int(cfg.pre_ln), patch_bias=int(cfg.patch_bias),
                            vocab=cfg.vocab, eos_id=cfg.eos_id, causal=int(cfg.causal),
-                           compute={"bf16": 0, "f32": 1, "fp8": 2, "fp8_all": 2, "fp8_strict": 2}[compute], ln_eps=cfg.ln_eps,
+                           compute={"bf16": 0, "f32": 1, "fp8": 2, "fp8_strict": 2, "fp8_mlp": 2, "fp8_all": 2}[compute], ln_eps=cfg.ln_eps,
                            fp8_sites=sites, fp8_mlp_cls_bf16=cls, fp8_first_layer=first)
         h = C.c_void_p()
         with torch.cuda.device(self.device):

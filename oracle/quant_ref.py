@@ -63,6 +63,25 @@ def quant_act_e4m3(a, mode):
     raise ValueError(mode)
 
 
+def add_outliers(cfg, w, ln_gain=64.0, fc1_gain=2000.0, channels=4, seed=1, compensate=True):
+    """Outlier stress for the e4m3 sites (trained CLIP towers have outlier channels; the random-init weights the presets were
+    budgeted on do not): in every block, `channels` LayerNorm-2 gains are multiplied by ln_gain (LN outputs of a few hundred: inside
+    e4m3's range, where its RELATIVE precision is what it is everywhere) and `channels` rows of fc1 (+ bias) by fc1_gain, which
+    drives those hidden activations far beyond 448 = the saturation point of the unit-scale e4m3 cast.  compensate=True divides
+    the matching fc2 columns by fc1_gain, so the float32 function stays well-conditioned and what is measured is the cast."""
+    w2 = {k: np.array(v, copy=True) for k, v in w.items()}
+    rng = np.random.default_rng(seed)
+    for i in range(cfg.layers):
+        ch = rng.choice(cfg.width, channels, replace=False)
+        w2[f"l{i}.ln2_g"][ch] *= ln_gain
+        rows = rng.choice(cfg.mlp, channels, replace=False)
+        w2[f"l{i}.fc1_w"][rows] *= fc1_gain
+        w2[f"l{i}.fc1_b"][rows] *= fc1_gain
+        if compensate:
+            w2[f"l{i}.fc2_w"][:, rows] /= fc1_gain
+    return w2
+
+
 class QuantSpec:
     """Which (layer, site) pairs run in e4m3; every other site runs in bf16 (f32 when `base` == "f32")."""
 

@@ -6,7 +6,9 @@ Two layers of checks, tolerances written here:
     (2^-3 relative, compared after dequantisation), float32 residual 1e-4 relative to the row scale;
   * the whole tower against the float32 HF golden vectors, per assignment of the four linear sites to e4m3
     (oracle/quant_ref.py + tools/fp8_error_budget.py give the CPU-emulated budget, profiles/r02_fp8_error_budget.json):
-      compute="fp8"      fc1 + fc2 in e4m3, token-0 rows of those sites in bf16: 1 - cos <= 1e-3 asserted (emulated 4-5e-4)
+      compute="fp8"      fc1 + fc2 in e4m3 in the last third of the blocks, token-0 rows bf16: the preset that meets the north-star
+                         bound (|score - f32 score| <= 1e-3 on every pair), 1 - cos <= 1e-4 asserted
+      compute="fp8_mlp"  the same in every block: 1 - cos <= 1e-3 asserted (emulated 4-5e-4)
       compute="fp8_all"  all four sites: e4m3 carries 3 mantissa bits, 1 - cos ~ 3-4e-3; asserted cosine >= 0.99
     and against the operand-rounding EMULATION of the same assignment, which pins where the kernels quantise;
   * configs[4] as one workload: ViT-L/14 e4m3 rows in a 768-d index, mixed text + image queries, ids exact against the
@@ -112,31 +114,67 @@ def test_vision_tower_fp8_all_sites(cfg, n, golden):
 
 
 @pytest.mark.parametrize("cfg,n", CASES, ids=lambda v: getattr(v, "name", str(v)))
-def test_vision_tower_fp8_default_assignment_within_1e3(cfg, n, golden):
-    """The shipped compute="fp8": MLP sites in e4m3, token-0 rows of those sites in bf16 -> inside the 1e-3 bound."""
+def test_vision_tower_fp8_mlp_assignment_within_1e3(cfg, n, golden):
+    """compute="fp8_mlp": MLP sites in e4m3 in every block, token-0 rows of those sites in bf16 -> 1 - cos inside 1e-3."""
     from test_tower_gpu import _cos, _vision
     g = golden("towers")
-    tw, _, _, out = _vision(cfg, "fp8", n)
-    assert tw.fp8_sites == 12 and tw.fp8_cls_bf16 == 1
+    tw, _, _, out = _vision(cfg, "fp8_mlp", n)
+    assert tw.fp8_sites == 12 and tw.fp8_cls_bf16 == 1 and tw.fp8_first_layer == 0
     ref = g[cfg.name + "_emb"][:n]
     cos = _cos(out, ref)
-    print(f"{cfg.name} fp8 (fc1+fc2 e4m3, token-0 rows bf16) 1 - min cos to fp32 HF = {1 - cos.min():.2e}")
+    print(f"{cfg.name} fp8_mlp (fc1+fc2 e4m3, token-0 rows bf16) 1 - min cos to fp32 HF = {1 - cos.min():.2e}")
     assert 1 - cos.min() <= 1e-3
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-5
 
 
 @pytest.mark.parametrize("cfg,n", CASES[1:], ids=lambda v: getattr(v, "name", str(v)))
-def test_vision_tower_fp8_strict_assignment(cfg, n, golden):
-    """compute="fp8_strict": MLP sites in e4m3 only in the last third of the blocks (+ bf16 token-0 rows): within a few times the
-    bf16 error, and equal to the CPU emulation's budget for that assignment."""
+def test_vision_tower_fp8_default_preset_is_the_one_inside_the_bound(cfg, n, golden):
+    """compute="fp8" (old name "fp8_strict"): MLP sites in e4m3 only in the last third of the blocks (+ bf16 token-0 rows): within
+    a few times the bf16 error, and equal to the CPU emulation's budget for that assignment."""
     from test_tower_gpu import _cos, _vision
     g = golden("towers")
-    tw, _, _, out = _vision(cfg, "fp8_strict", n)
+    tw, _, _, out = _vision(cfg, "fp8", n)
     assert tw.fp8_first_layer == (2 * cfg.layers) // 3 and tw.fp8_sites == 12 and tw.fp8_cls_bf16 == 1
+    old, _, _, out_old = _vision(cfg, "fp8_strict", n)
+    assert (old.fp8_first_layer, old.fp8_sites, old.fp8_cls_bf16) == (tw.fp8_first_layer, tw.fp8_sites, tw.fp8_cls_bf16)
+    assert np.array_equal(out, out_old)
     ref = g[cfg.name + "_emb"][:n]
     cos = _cos(out, ref)
-    print(f"{cfg.name} fp8_strict (fc1+fc2 e4m3 in blocks >= {tw.fp8_first_layer}, token-0 rows bf16) 1 - min cos to fp32 HF = {1 - cos.min():.2e}")
+    print(f"{cfg.name} fp8 (fc1+fc2 e4m3 in blocks >= {tw.fp8_first_layer}, token-0 rows bf16) 1 - min cos to fp32 HF = {1 - cos.min():.2e}")
     assert 1 - cos.min() <= 1e-4
+
+
+def test_fp8_presets_under_outlier_channels():
+    """Outlier stress: LayerNorm-2 gains x64 on four channels and four fc1 rows x2000 per block (fc2 columns divided
+    back) put LN outputs at a few hundred and hidden activations at thousands - far beyond 448, where the unit-scale e4m3 cast
+    saturates.  The HIP towers must saturate exactly where the emulation does (oracle/quant_ref.py: clamp, then RNE), and the
+    measured cost is asserted: the preset inside the north-star bound is unaffected (its e4m3 blocks are the last third and the
+    pooled token-0 rows stay bf16), fp8_mlp roughly doubles its error and stays inside 2e-3.  Emulated per-row activation scales
+    halve fp8_mlp's error here (printed by tools/fp8_error_budget.py --outliers) - not needed for the shipped bound."""
+    from ivr_amd.tower import Tower
+    from ivr_amd.weights import make_weights
+    from conftest import synth_frames
+    from oracle import preprocess_ref as P
+    from oracle import quant_ref as QR
+    from oracle import vit_ref as V
+    cfg = C.CLIP_VIT_B32
+    w = QR.add_outliers(cfg, make_weights(cfg, 12))
+    frames = synth_frames(99, 6, 224, 224)
+    px = P.preprocess(frames, "identity", C.CLIP_MEAN, C.CLIP_STD)
+    ref = V.vision_forward(cfg, w, px)
+    L = cfg.layers
+    specs = {"fp8": QR.QuantSpec(("fc1", "fc2"), fp8_layers=range(2 * L // 3, L), keep_rows=(0,)),
+             "fp8_mlp": QR.QuantSpec(("fc1", "fc2"), keep_rows=(0,))}
+    limit = {"fp8": 1e-4, "fp8_mlp": 2e-3}
+    for compute, spec in specs.items():
+        spec.keep_sites = {"fc1", "fc2"}
+        emu = QR.vision_forward(cfg, w, px, spec)
+        out = Tower(cfg, w, max_batch=6, compute=compute).encode_frames(frames).cpu().numpy()
+        assert np.isfinite(out).all()
+        d_ref, d_emu, e_ref = 1 - (out * ref).sum(1).min(), 1 - (out * emu).sum(1).min(), 1 - (emu * ref).sum(1).min()
+        print(f"outliers {compute}: 1-cos gpu/f32 {d_ref:.2e}, emulation/f32 {e_ref:.2e}, gpu/emulation {d_emu:.2e}")
+        assert d_ref <= limit[compute]
+        assert 0.5 * e_ref - 2e-5 <= d_ref <= 1.6 * e_ref + 2e-5
 
 
 SITE_SETS = [("qkv",), ("o",), ("fc1",), ("fc2",), ("fc1", "fc2"), ("qkv", "o", "fc1", "fc2")]
@@ -178,14 +216,15 @@ def test_fp8_site_assignments_match_emulation(sites, cls_bf16):
 
 
 def test_config4_workload_fp8_rows_mixed_queries():
-    """BASELINE configs[4] at test scale as ONE workload: ViT-L/14 rows from the e4m3 tower in a 768-d index, a mixed batch of
-    image queries (same e4m3 tower) and text queries (bf16 text tower), exact top-k through the HIP search.
+    """BASELINE configs[4] at test scale as ONE workload: 64 ViT-L/14 rows from the e4m3 tower in a 768-d index, a mixed batch of 16
+    image queries (same e4m3 tower) and 16 text queries, exact top-k through the HIP search.
       ids: bit-exact against the oracle search over the SAME rows and queries;
-      scores: against the float32 oracle towers' scores for the same frames / token ids (text queries from the f32 text tower: a
-      handful of queries costs nothing, and the bf16 text tower alone moves these scores by up to 1.1e-3).  The north-star bound
-      is 1e-3: compute="fp8_strict" (e4m3 MLP in the last third of the blocks) is asserted against it on every pair;
-      compute="fp8" (e4m3 MLP in every block) keeps the image-query scores and 1 - cos inside 1e-3 and is asserted against
-      3e-3 on text-vs-image scores; profiles/r02_fp8_error_budget.json has the whole table."""
+      scores: all 64 x 32 pairs against the float32 oracle towers' scores for the same frames / token ids (text queries from the
+      f32 text tower: a handful of queries costs nothing, and the bf16 text tower alone moves these scores by up to 1.1e-3).
+    The north-star bound is 1e-3 on every pair: compute="fp8" IS the assignment that meets it (asserted on the max over the
+    2,048 pairs and on every top-k pair; max and p99 printed per preset).  "fp8_mlp" (e4m3 MLP in every block) keeps the embedding
+    bound 1 - cos <= 1e-3 and is asserted at 3e-3 on the scores; "fp8_all" at 1e-2.  Random-init weights (no trained checkpoint is
+    reachable offline): profiles/r02_fp8_error_budget.json has the emulated table the presets come from."""
     from ivr_amd.index import FlatIPIndex
     from ivr_amd.tower import Tower
     from ivr_amd.weights import make_weights
@@ -195,7 +234,7 @@ def test_config4_workload_fp8_rows_mixed_queries():
     from oracle import vit_ref as V
     vis, txt = C.CLIP_VIT_L14, C.CLIP_TEXT_L14
     wv, wt = make_weights(vis, 12), make_weights(txt, 13)
-    n_rows, n_iq, n_tq, k = 10, 2, 6, 5
+    n_rows, n_iq, n_tq, k = 64, 16, 16, 10
     frames = synth_frames(1234, n_rows + n_iq, 224, 224)
     rng = np.random.default_rng(77)
     ids = rng.integers(1, txt.vocab - 2, (n_tq, 16)).astype(np.int64)
@@ -203,8 +242,12 @@ def test_config4_workload_fp8_rows_mixed_queries():
         ids[r, rng.integers(4, 16):] = txt.eos_id
     results = {}
     tq = Tower(txt, wt, max_batch=n_tq, compute="f32").encode_ids(ids)     # a handful of queries: the f32 text tower costs nothing
-    for compute in ("fp8_strict", "fp8", "fp8_all", "bf16"):
-        emb = Tower(vis, wv, max_batch=n_rows + n_iq, compute=compute).encode_frames(frames)
+    for compute in ("fp8", "fp8_mlp", "fp8_all", "bf16"):
+        tw = Tower(vis, wv, max_batch=n_rows + n_iq, compute=compute)
+        if compute == "fp8":
+            assert tw.fp8_first_layer == (2 * vis.layers) // 3           # the default e4m3 preset is the one inside the bound
+        emb = tw.encode_frames(frames)
+        tw.close()
         idx = FlatIPIndex(768)
         idx.add(emb[:n_rows])
         queries = torch.cat([emb[n_rows:], tq])
@@ -213,21 +256,22 @@ def test_config4_workload_fp8_rows_mixed_queries():
         Dr, Ir = S.flat_ip_search(rows_h, q_h, k, dtype=np.float64)
         assert np.array_equal(I.cpu().numpy(), Ir), compute               # ids exact over the same rows
         assert np.abs(D.cpu().numpy() - Dr).max() < 1e-5
-        results[compute] = (rows_h, q_h)
-    px = P.preprocess(frames, "identity", C.CLIP_MEAN, C.CLIP_STD)
-    ref = V.vision_forward(vis, wv, px)
+        results[compute] = (rows_h, q_h, I.cpu().numpy())
+    ref = np.concatenate([V.vision_forward(vis, wv, P.preprocess(frames[i:i + 16], "identity", C.CLIP_MEAN, C.CLIP_STD))
+                          for i in range(0, len(frames), 16)])
     tref = V.text_forward(txt, wt, ids)
     Sref = np.concatenate([ref[n_rows:], tref]) @ ref[:n_rows].T
     worst = {}
-    for compute, (rows_h, q_h) in results.items():
+    for compute, (rows_h, q_h, I) in results.items():
         d = np.abs(q_h @ rows_h.T - Sref)
-        worst[compute] = (d[:n_iq].max(), d[n_iq:].max(), 1 - (rows_h * ref[:n_rows]).sum(1).min())
-        print(f"configs[4] {compute:8s}: max |score - f32 oracle score| image queries {d[:n_iq].max():.2e}, text queries {d[n_iq:].max():.2e}; "
-              f"1 - min cos of the rows {worst[compute][2]:.2e}")
+        topk = np.take_along_axis(d, I, axis=1)                            # the pairs a caller actually sees
+        worst[compute] = (d[:n_iq].max(), d[n_iq:].max(), 1 - (rows_h * ref[:n_rows]).sum(1).min(), topk.max())
+        print(f"configs[4] {compute:8s} |score - f32 oracle score| over {d.size} pairs: image queries max {d[:n_iq].max():.2e} p99 "
+              f"{np.quantile(d[:n_iq], 0.99):.2e}, text queries max {d[n_iq:].max():.2e} p99 {np.quantile(d[n_iq:], 0.99):.2e}, top-{k} pairs max "
+              f"{topk.max():.2e}; 1 - min cos of the rows {worst[compute][2]:.2e}")
     assert worst["bf16"][1] <= 1e-3 and worst["bf16"][0] <= 1e-3
-    assert worst["fp8_strict"][0] <= 1e-3 and worst["fp8_strict"][1] <= 1e-3 and worst["fp8_strict"][2] <= 1e-4     # the north-star bound, every pair
-    assert worst["fp8"][2] <= 1e-3 and worst["fp8"][0] <= 1e-3           # embedding bound and image-query scores inside 1e-3
-    assert worst["fp8"][1] <= 3e-3                                        # text-vs-image scores: e4m3 in every block, see docstring
+    assert max(worst["fp8"][0], worst["fp8"][1], worst["fp8"][3]) <= 1e-3 and worst["fp8"][2] <= 1e-4       # the north-star bound, every pair
+    assert worst["fp8_mlp"][2] <= 1e-3 and worst["fp8_mlp"][1] <= 3e-3 and worst["fp8_mlp"][0] <= 3e-3
     assert worst["fp8_all"][1] <= 1e-2
 
 
@@ -241,7 +285,7 @@ def test_text_tower_fp8_mode(golden):
     ids = rng.integers(0, cfg.vocab - 1, (6, cfg.tokens))
     ids[:, -3] = cfg.eos_id
     ref = np.asarray(V.text_forward(cfg, w, ids))
-    for compute in ("fp8", "fp8_all"):        # text towers pool at the EOS token: no token-0 side path, plain site masks
+    for compute in ("fp8_mlp", "fp8_all"):    # text towers pool at the EOS token: no token-0 side path, plain site masks
         out = Tower(cfg, w, max_batch=8, compute=compute).encode_ids(ids).cpu().numpy()
         cos = (out * ref).sum(1) / (np.linalg.norm(out, axis=1) * np.linalg.norm(ref, axis=1))
         print(f"tiny-text {compute} min cos={cos.min():.5f}")

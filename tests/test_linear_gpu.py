@@ -81,3 +81,30 @@ def test_bad_shapes():
     w = torch.zeros((8, 100), dtype=torch.bfloat16, device="cuda")
     with pytest.raises(ValueError):
         linear(x, w)                                            # K not a multiple of 64
+
+
+def test_row_operand_beyond_2gib_runs_in_slabs():
+    """the kernels reach 2 GiB through their 32-bit buffer offsets; a taller row operand (here 1.1M x 1024 bf16
+    = 2.25 GB, what ViT-B/32 reaches from ~6.8k frames per step) is run as slabs of whole 256-row tiles.  Store and residual
+    epilogues, rows on both sides of every slab boundary and the last row checked against a float32 product."""
+    from ivr_amd.linear import EPI_RESID, linear
+    M, N, K = 1_100_003, 64, 1024
+    assert M * K * 2 > 2 ** 31
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.empty((M, K), dtype=torch.bfloat16, device="cuda")
+    for i in range(0, M, 200_000):
+        x[i:i + 200_000] = (torch.randn((min(200_000, M - i), K), generator=g, device="cuda") * 0.7).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    y = linear(x, w, b)
+    slab = (0x7ffffff0 // (K * 2)) // 256 * 256
+    rows = torch.tensor(sorted({0, 1, 255, 256, slab - 1, slab, slab + 1, slab + 257, M - 2, M - 1} | set(range(slab - 300, slab + 300, 37))),
+                        device="cuda")
+    ref = x[rows].float() @ w.float().T + b
+    assert (y[rows].float() - ref).abs().max() <= 1.2e-2 * max(1.0, float(ref.abs().max()))
+    # every row was written: an unwritten slab would leave torch.empty garbage, caught by a checksum against a chunked product
+    tot = sum(float((x[i:i + 100_000].float() @ w.float().T + b).double().sum()) for i in range(0, M, 100_000))
+    assert abs(float(y.double().sum()) - tot) <= 2e-3 * M ** 0.5 * N ** 0.5 + 1e-6 * abs(tot) + 50.0
+    r = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    linear(x, w, b, epilogue=EPI_RESID, resid=r)
+    assert (r[rows] - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))

@@ -123,3 +123,25 @@ def test_emulation_reduces_to_its_limits():
     for mode in ("none", "row", "row_pow2", "block32"):
         aq, s = QR.quant_act_e4m3(torch.from_numpy(px.reshape(3, -1)[:, :256].copy()), mode)
         assert torch.isfinite(aq).all()
+
+
+def test_outlier_stress_saturates_the_unit_scale_cast_and_row_scales_recover_it():
+    """oracle/quant_ref.add_outliers drives hidden activations beyond 448: the unit-scale e4m3 cast of the emulation saturates there
+    (what the HIP fc1 epilogue does, tests/test_fp8_gpu.py), per-row scales do not; the float32 function itself stays finite."""
+    from ivr_amd import config as C
+    from ivr_amd.weights import make_weights
+    from oracle import quant_ref as QR
+    from oracle import vit_ref as V
+    cfg = C.TINY_VIT
+    w0 = make_weights(cfg, 11)
+    w = QR.add_outliers(cfg, w0, ln_gain=64.0, fc1_gain=50000.0, channels=2)
+    assert not np.array_equal(w["l0.fc1_w"], w0["l0.fc1_w"]) and np.array_equal(w["l0.q_w"], w0["l0.q_w"])
+    px = np.random.default_rng(0).standard_normal((3, 3, cfg.image, cfg.image)).astype(np.float32)
+    ref = V.vision_forward(cfg, w, px)
+    assert np.isfinite(ref).all()
+    unit = QR.vision_forward(cfg, w, px, QR.QuantSpec(("fc1", "fc2")))
+    row = QR.vision_forward(cfg, w, px, QR.QuantSpec(("fc1", "fc2"), act_scale="row"))
+    e_unit, e_row = 1 - (unit * ref).sum(1).min(), 1 - (row * ref).sum(1).min()
+    assert np.isfinite(unit).all() and e_row < e_unit
+    x = torch.tensor([1000.0, -3000.0, 448.0, 500.0])
+    assert QR.e4m3_round(x).tolist() == [448.0, -448.0, 448.0, 448.0]

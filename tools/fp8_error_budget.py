@@ -38,10 +38,14 @@ def main():
     ap.add_argument("--text-queries", type=int, default=8)
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true", help="single sites + all four only")
+    ap.add_argument("--outliers", action="store_true",
+                    help="budget on the outlier-stressed weights of oracle/quant_ref.add_outliers (LN-2 gains x64, fc1 rows x2000)")
     args = ap.parse_args()
     torch.set_num_threads(len(os.sched_getaffinity(0)))
     vcfg, tcfg = (C.CLIP_VIT_L14, C.CLIP_TEXT_L14) if args.tower == "l14" else (C.CLIP_VIT_B32, C.CLIP_TEXT_B32)
     wv, wt = make_weights(vcfg, 12), make_weights(tcfg, 13)
+    if args.outliers:
+        wv = QR.add_outliers(vcfg, wv)
     n = args.frames + args.image_queries
     frames = np.random.default_rng(1234).integers(0, 256, (n, 224, 224, 3), dtype=np.uint8)
     px = P.preprocess(frames, "identity", C.CLIP_MEAN, C.CLIP_STD)
@@ -94,7 +98,7 @@ def main():
         spec = QR.QuantSpec(sub, keep_rows=(0,))
         spec.keep_sites = {"fc1", "fc2"}
         run(f"e4m3 {'+'.join(sub)} / token-0 rows of fc1, fc2 in bf16", spec)
-    # ... and only from block `first` on (tower desc fp8_first_layer): compute="fp8_strict" is first = 2L/3
+    # ... and only from block `first` on (tower desc fp8_first_layer): compute="fp8" (old name "fp8_strict") is first = 2L/3
     if not args.quick:
         L = vcfg.layers
         for first in (L // 3, L // 2, (2 * L) // 3, (5 * L) // 6):
