@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define IVR_API_VERSION 3
+#define IVR_API_VERSION 4
 #define IVR_MAX_K 2048          /* reference: k=50 default, SearchOptions.limit <= 1000 (system.py:91) */
 
 typedef enum ivr_status {
@@ -230,6 +230,12 @@ int ivr_dedup_keep_mask(ivr_ctx *ctx, const float *emb /*DEV*/, int n, int d, fl
  * last kept frame and cos(emb[i], emb[last kept]) < threshold (the caller appends the scene's last frame, filter.py:218-220). */
 int ivr_scene_keep_mask(ivr_ctx *ctx, const float *emb /*DEV*/, int n, int d, float threshold, int min_distance,
                         uint8_t *keep /*DEV*/, ivr_stream stream);
+
+/* Window variant, filter_similar_frames_advanced at filter.py:224-258 (selected by use_advanced_similarity_filtering, filter.py:292-295):
+ * keep[0] = 1; keep[i] = 1 iff no KEPT frame j in [i - min(window, n), i) has cos(emb[i], emb[j]) >= threshold.  Two launches: the
+ * banded cosines in parallel, then the decision chain over n x window floats. */
+int ivr_scene_keep_mask_window(ivr_ctx *ctx, const float *emb /*DEV*/, int n, int d, float threshold, int window,
+                               uint8_t *keep /*DEV*/, ivr_stream stream);
 
 /* cos(a[i], b[i]) for i < n (DEV float32 [n,d] each), sklearn cosine_similarity conventions.  Replaces the per-pair
  * cosine_similarity([x],[y])[0][0] calls of the keyframe filter (filter.py:147, filter.py:208). */

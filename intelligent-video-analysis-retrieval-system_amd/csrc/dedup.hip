@@ -5,6 +5,7 @@
 // where prev_embedding is the embedding of the last KEPT frame.  The decision chain is sequential,
 // so one wave walks the batch in frame order; per frame it needs one dot product and one squared norm
 // (the kept frame's norm is carried), reduced with wave shuffles - no host round trip.
+#include <algorithm>
 #include <type_traits>
 
 #include "ivr_common.h"
@@ -125,7 +126,61 @@ __global__ __launch_bounds__(256) void rowwise_cosine_kernel(const float *__rest
     if (lane == 0) out[row] = dot / (na * nb);
 }
 
+// Window mode of the in-scene filter (filter_similar_frames_advanced, filter.py:224-258): frame i is kept iff no KEPT frame j in
+// [i - window, i) has cos(e_i, e_j) >= threshold.  The cosines of every frame with its `window` predecessors do not depend on the
+// decisions, so they are computed first by all the waves of the launch (band[i][t-1] = cos(e_i, e_{i-t})); the decision chain is
+// then a walk over n x window floats by one thread - no embedding is touched twice by the sequential part.
+__global__ __launch_bounds__(256) void band_cosine_kernel(const float *__restrict__ emb, int n, int d, int window, float *__restrict__ band) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (int64_t)n * window) return;
+    const int i = (int)(pair / window), t = (int)(pair % window) + 1;
+    if (i - t < 0) return;
+    const float *pa = emb + (int64_t)i * d, *pb = emb + (int64_t)(i - t) * d;
+    float dot = 0.f, sa = 0.f, sb = 0.f;
+    for (int k = lane; k < d; k += 64) {
+        const float x = pa[k], y = pb[k];
+        dot = fmaf(x, y, dot);
+        sa = fmaf(x, x, sa);
+        sb = fmaf(y, y, sb);
+    }
+    dot = ivr_wave_sum(dot);
+    sa = ivr_wave_sum(sa);
+    sb = ivr_wave_sum(sb);
+    const float na = sa > 0.f ? sqrtf(sa) : 1.f, nb = sb > 0.f ? sqrtf(sb) : 1.f;      // sklearn: zero norm -> 1
+    if (lane == 0) band[pair] = dot / (na * nb);
+}
+
+__global__ void window_chain_kernel(const float *__restrict__ band, int n, int window, float threshold, uint8_t *__restrict__ keep) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) {
+        bool k = true;
+        for (int t = 1; t <= window && t <= i && k; ++t)
+            if (keep[i - t] && band[(int64_t)i * window + t - 1] >= threshold) k = false;
+        keep[i] = k ? 1 : 0;
+    }
+}
+
 }  // namespace
+
+extern "C" int ivr_scene_keep_mask_window(ivr_ctx *ctx, const float *emb, int n, int d, float threshold, int window, uint8_t *keep,
+                                          ivr_stream stream) {
+    IVR_REQUIRE(ctx && (n == 0 || (emb && keep)), "ivr_scene_keep_mask_window: NULL argument");
+    IVR_REQUIRE(n >= 0 && d >= 1 && window >= 1, "ivr_scene_keep_mask_window: n=%d d=%d window=%d", n, d, window);
+    if (n == 0) return IVR_OK;
+    IVR_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    window = std::min(window, n);                                   // filter.py:233
+    std::lock_guard<std::mutex> enqueue(ctx->enqueue_mu);           // the two launches share the stream's scratch block
+    void *scratch = nullptr;
+    if (int rc = ivr_ctx_scratch(ctx, s, (size_t)n * window * sizeof(float), &scratch)) return rc;
+    float *band = reinterpret_cast<float *>(scratch);
+    hipLaunchKernelGGL(band_cosine_kernel, dim3((unsigned)ivr_ceil_div((int64_t)n * window, 4)), dim3(256), 0, s, emb, n, d, window, band);
+    IVR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(window_chain_kernel, dim3(1), dim3(64), 0, s, band, n, window, threshold, keep);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
 
 extern "C" int ivr_rowwise_cosine(ivr_ctx *ctx, const float *a, const float *b, int n, int d, float *out, ivr_stream stream) {
     IVR_REQUIRE(ctx && (n == 0 || (a && b && out)), "ivr_rowwise_cosine: NULL argument");

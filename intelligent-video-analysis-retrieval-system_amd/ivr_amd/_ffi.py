@@ -26,7 +26,7 @@ class TowerDesc(C.Structure):
                                                                       ("fp8_first_layer", C.c_int)]
 
 
-API_VERSION = 3
+API_VERSION = 4
 FP8_SITE = {"qkv": 1, "o": 2, "fc1": 4, "fc2": 8}
 
 
@@ -72,6 +72,7 @@ _SIGS = {
     "ivr_rowwise_cosine": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "ivr_dedup_keep_mask": (_i, [_p, _p, _i, _i, _f, _p, _p, _p]),
     "ivr_scene_keep_mask": (_i, [_p, _p, _i, _i, _f, _i, _p, _p]),
+    "ivr_scene_keep_mask_window": (_i, [_p, _p, _i, _i, _f, _i, _p, _p]),
     "ivr_frame_quality_scratch_bytes": (_i64, [_i, _i, _i]),
     "ivr_frame_quality": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
 }

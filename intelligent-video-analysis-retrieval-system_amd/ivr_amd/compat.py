@@ -812,8 +812,31 @@ class FrameFilter:
     def extract_frames(self, video_path, keyframe_root="keyframes", map_root="map", batch=64):
         return extract_unique_frames(video_path, keyframe_root, map_root, frame_filter=self, batch=batch)
 
-    def apply_filters(self, frames_bgr):
-        return [f for f, k in zip(frames_bgr, self.filter_frames(np.asarray(frames_bgr))) if k]
+    def apply_filters(self, frames, config=None, bgr=True, return_details=False):
+        """README alias (README.md:196, SURVEY.md Fact 1 maps it to filter.py:317): the keyframe filter of
+        filter_transition_frames_for_video over decoded frames - quality gating (blur / edge density) of all frames in batches,
+        DINO embeddings of the accepted frames only, scene split, in-scene similarity filter - as batched GPU passes
+        (ivr_amd.filters.filter_keyframes).  frames: list / array of uint8 [h,w,3] (bgr=True: cv2 order).  Returns the kept frames
+        (or the details dict); [] where the reference returns None (too few acceptable frames, no valid scene)."""
+        from .filters import filter_keyframes
+        rgb = [None if f is None else np.ascontiguousarray(np.asarray(f)[..., ::-1] if bgr else np.asarray(f)) for f in frames]
+
+        def embed(batch):
+            # frames of one call may differ in size: the stretch resize is per frame size
+            embs = [None] * len(batch)
+            groups = {}
+            for i, b in enumerate(batch):
+                groups.setdefault(b.shape, []).append(i)
+            for shape, idxs in groups.items():
+                mode = "identity" if shape[:2] == (224, 224) else "stretch"
+                e = self.tower.encode_frames(np.stack([batch[i] for i in idxs]), mode, self.mean, self.std, normalize=False)
+                for j, i in enumerate(idxs):
+                    embs[i] = e[j]
+            return torch.stack(embs)
+        res = filter_keyframes(rgb, embed, config, quality_batch=min(64, self.tower.max_batch))
+        if return_details:
+            return res
+        return [] if res is None else [frames[i] for i in res["kept"]]
 
 
 _default_filter = None

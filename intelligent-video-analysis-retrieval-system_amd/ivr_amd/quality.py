@@ -31,6 +31,8 @@ def frame_quality_scores(frames, bgr=False, canny_low=CANNY_LOW, canny_high=CANN
     if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
         raise ValueError("frames must be uint8 [n,h,w,3]")
     frames = frames.cuda().contiguous() if not frames.is_cuda else frames.contiguous()
+    if frames.data_ptr() % 16:                      # the tile kernel fetches 16-byte chunks: a view into a larger batch may start anywhere
+        frames = frames.clone()
     n, h, w, _ = frames.shape
     if n == 0:
         return []

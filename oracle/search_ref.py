@@ -195,6 +195,89 @@ def filter_similar_frames_in_scene(scene_embeddings, scene_indices, config):
     return [scene_indices[i] for i in kept]
 
 
+def filter_similar_frames_advanced(scene_embeddings, scene_indices, config):
+    """filter.py:224-258, line by line: keep frame i unless a KEPT frame j in [i - window, i) has cosine >= threshold
+    (window = min(similarity_window_size, len(scene)), filter.py:233)."""
+    if not config["enable_similarity_filtering"] or len(scene_embeddings) <= 1:
+        return scene_indices
+    thr = config["similarity_threshold"]
+    window = min(config["similarity_window_size"], len(scene_embeddings))
+    kept = [0]
+    for i in range(1, len(scene_embeddings)):
+        should_keep = True
+        for j in range(max(0, i - window), i):
+            if j in kept and cosine_1x1(scene_embeddings[i], scene_embeddings[j]) >= thr:
+                should_keep = False
+                break
+        if should_keep:
+            kept.append(i)
+    return [scene_indices[i] for i in kept]
+
+
+def group_into_scenes(transition_points, total_frames, min_length):
+    """filter.py:160-176."""
+    scenes, start = [], 0
+    for t in transition_points:
+        if t - start >= min_length:
+            scenes.append((start, t - 1))
+        start = t
+    if total_frames - start >= min_length:
+        scenes.append((start, total_frames - 1))
+    return scenes
+
+
+def keyframe_pipeline(quality_scores, embed_fn, config):
+    """filter_transition_frames_for_video, filter.py:317-470, without its file I/O: per-frame quality scores (phase 1) ->
+    thresholds (phase 2, np.percentile when adaptive) -> acceptance (phase 3; only accepted frames are embedded, embed_fn(i) may
+    return None) -> consecutive cosines, scene cuts, scenes (phase 4) -> in-scene similarity filter, window variant when
+    use_advanced_similarity_filtering (phase 5).  Returns the kept positions (indices into the input order) and the statistics
+    the reference prints, or None where the reference returns None."""
+    n = len(quality_scores)
+    if n == 0:
+        return None
+    if config["enable_adaptive_filtering"]:
+        bt = np.percentile([q["blur_score"] for q in quality_scores], config["blur_percentile"])
+        et = np.percentile([q["edge_density"] for q in quality_scores], config["edge_percentile"])
+    else:
+        bt, et = config["blur_threshold"], config["edge_threshold"]
+    stats = {"blur": 0, "low_edge": 0, "acceptable": 0, "embedding_error": 0}
+    positions, embeddings = [], []
+    for i, q in enumerate(quality_scores):
+        reason = "acceptable"
+        if config["enable_blur_detection"] and bt is not None and q["blur_score"] < bt:
+            reason = "blur"
+        elif config["enable_edge_detection"] and et is not None and q["edge_density"] < et:
+            reason = "low_edge"
+        if reason != "acceptable":
+            stats[reason] += 1
+            continue
+        e = embed_fn(i)
+        if e is None:
+            stats["embedding_error"] += 1
+            continue
+        stats["acceptable"] += 1
+        positions.append(i)
+        embeddings.append(e)
+    if len(embeddings) < config["min_scene_length"]:
+        return None
+    sims = consecutive_similarities(embeddings)
+    transitions = [i + 1 for i, s_ in enumerate(sims) if s_ < config["transition_threshold"]]
+    scenes = group_into_scenes(transitions, len(embeddings), config["min_scene_length"])
+    if not scenes:
+        return None
+    kept = []
+    for a, b in scenes:
+        idx = list(range(a, b + 1))
+        if not config["enable_similarity_filtering"]:
+            kept.extend(idx)
+        elif config.get("use_advanced_similarity_filtering", False):
+            kept.extend(filter_similar_frames_advanced(embeddings[a:b + 1], idx, config))
+        else:
+            kept.extend(filter_similar_frames_in_scene(embeddings[a:b + 1], idx, config))
+    return {"kept": [positions[i] for i in kept], "quality_stats": stats, "scenes": scenes, "transitions": transitions,
+            "avg_similarity": float(np.mean(sims)) if sims else float("nan"), "blur_threshold": bt, "edge_threshold": et}
+
+
 def similarity_graph(features, keys, top=10, threshold=0.7):
     """core.py:3513-3526 with sklearn's cosine_similarity restated (row-normalise, then X X^T)."""
     f = np.asarray(features, dtype=np.float64)

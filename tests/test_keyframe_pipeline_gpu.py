@@ -1,0 +1,158 @@
+"""GPU: the keyframe filter of filter.py:224-470 as batched passes - window variant of the in-scene filter
+(ivr_scene_keep_mask_window), the pipeline driver (ivr_amd.filters.filter_keyframes) and FrameFilter.apply_filters -
+against the line-by-line restatements in oracle/search_ref.py (quality scores from oracle/quality_ref.py, parity unpinned:
+cv2 is absent and the reference holds no fixture)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import smooth_frames, synth_frames
+from oracle import quality_ref as Q
+from oracle import search_ref as S
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"enable_similarity_filtering": True, "similarity_threshold": 0.95, "min_frame_distance": 1, "similarity_window_size": 5,
+       "use_advanced_similarity_filtering": True, "transition_threshold": 0.75, "min_scene_length": 2, "enable_adaptive_filtering": True,
+       "blur_threshold": 10.0, "edge_threshold": 5.0, "enable_blur_detection": True, "enable_edge_detection": True,
+       "blur_percentile": 10.0, "edge_percentile": 10.0}
+
+
+def _walk(rng, n, d, step):
+    """Embeddings that drift: consecutive cosines around cos(step), with occasional jumps (scene cuts)."""
+    e = [rng.standard_normal(d)]
+    for i in range(1, n):
+        if rng.random() < 0.08:
+            e.append(rng.standard_normal(d))
+        else:
+            v = e[-1] / np.linalg.norm(e[-1]) + step * rng.uniform(0.2, 1.8) * rng.standard_normal(d) / np.sqrt(d)
+            e.append(v * rng.uniform(0.5, 2.0))
+    return np.asarray(e, np.float32)
+
+
+@pytest.mark.parametrize("n,d,window", [(2, 384, 5), (40, 384, 1), (257, 384, 5), (1000, 512, 3), (300, 48, 8), (64, 768, 200)])
+def test_window_keep_mask_matches_oracle(n, d, window):
+    from ivr_amd.filters import filter_similar_frames_advanced
+    rng = np.random.default_rng(n + d + window)
+    e = _walk(rng, n, d, 0.25)
+    cfg = dict(CFG, similarity_window_size=window)
+    ref = S.filter_similar_frames_advanced(list(e), list(range(100, 100 + n)), cfg)
+    # decisions at the threshold are not comparable across float32 summation orders: none may sit closer than 1e-5
+    en = e / np.linalg.norm(e, axis=1, keepdims=True)
+    sims = np.concatenate([np.sum(en[t:] * en[:-t], axis=1) for t in range(1, min(window, n - 1) + 1)])
+    assert np.abs(sims - cfg["similarity_threshold"]).min() > 1e-5
+    got = filter_similar_frames_advanced(e, list(range(100, 100 + n)), cfg)
+    assert got == ref
+    assert 1 < len(ref) < n or n <= 2
+    assert filter_similar_frames_advanced(torch.from_numpy(e).cuda(), list(range(n)), dict(cfg, enable_similarity_filtering=False)) == list(range(n))
+
+
+def _video(seed, n, h, w):
+    """A synthetic 'video': scenes of one smooth frame drifting by small noise, with blurred (box-filtered) and flat frames."""
+    rng = np.random.default_rng(seed)
+    frames, base = [], None
+    for i in range(n):
+        if base is None or rng.random() < 0.15:
+            base = smooth_frames(int(rng.integers(1 << 30)), 1, h, w)[0].astype(np.float32)
+        f = base + rng.uniform(0, 14) * rng.standard_normal(base.shape)
+        kind = rng.random()
+        if kind < 0.12:                                  # blurred: 9 x 9 box filter
+            k = 9
+            pad = np.pad(f, ((k // 2, k // 2), (k // 2, k // 2), (0, 0)), mode="edge")
+            f = sum(pad[a:a + h, b:b + w] for a in range(k) for b in range(k)) / (k * k)
+        elif kind < 0.2:                                 # nearly flat
+            f = 0.03 * f + 120
+        frames.append(np.clip(f, 0, 255).astype(np.uint8))
+        base = base + rng.uniform(0, 3) * rng.standard_normal(base.shape)
+    return frames
+
+
+def _embed_np(frames):
+    """A deterministic embedder the test controls on both sides: 6 x 8 block means of every channel (144-d), float64."""
+    out = []
+    for f in frames:
+        h, w, _ = f.shape
+        a = f[: h // 6 * 6, : w // 8 * 8].astype(np.float64).reshape(6, h // 6, 8, w // 8, 3).mean(axis=(1, 3))
+        out.append((a - a.mean()).ravel())
+    return np.asarray(out, np.float32)
+
+
+@pytest.mark.parametrize("advanced", [True, False])
+@pytest.mark.parametrize("adaptive", [True, False])
+def test_filter_keyframes_matches_the_oracle_pipeline(advanced, adaptive):
+    from ivr_amd.filters import filter_keyframes
+    frames = _video(11, 90, 72, 96)
+    frames[17] = None                                    # an unreadable file
+    cfg = dict(CFG, use_advanced_similarity_filtering=advanced, enable_adaptive_filtering=adaptive, blur_percentile=15.0, edge_percentile=15.0,
+               blur_threshold=60.0, edge_threshold=3.0, similarity_threshold=0.97)
+    calls = []
+
+    def embed_batch(batch):
+        calls.append(len(batch))
+        return torch.from_numpy(_embed_np(batch)).cuda()
+    res = filter_keyframes(frames, embed_batch, cfg, rows=[f"row{i}" for i in range(len(frames))], quality_batch=32)
+    scores = [Q.quality_scores(f) if f is not None else {"blur_score": 0.0, "edge_density": 0.0} for f in frames]
+    ref = S.keyframe_pipeline(scores, lambda i: None if frames[i] is None else _embed_np([frames[i]])[0], cfg)
+    assert res is not None and ref is not None
+    for g, r in zip(res["quality_scores"], scores):
+        assert abs(g["blur_score"] - r["blur_score"]) <= 1e-9 * max(1.0, r["blur_score"]) and abs(g["edge_density"] - r["edge_density"]) < 1e-9
+    assert res["quality_stats"] == ref["quality_stats"] or (res["quality_stats"]["embedding_error"] + res["quality_stats"]["acceptable"]
+                                                            == ref["quality_stats"]["embedding_error"] + ref["quality_stats"]["acceptable"])
+    assert res["transitions"] == ref["transitions"] and res["scenes"] == ref["scenes"]
+    assert res["kept"] == ref["kept"]
+    assert res["rows"] == [f"row{i}" for i in ref["kept"]]
+    assert res["embeddings"].shape == (len(ref["kept"]), 144)
+    assert sum(calls) == res["quality_stats"]["acceptable"] and max(calls) <= 32        # accepted frames only, batched
+    assert 3 < len(ref["kept"]) < res["quality_stats"]["acceptable"]
+    assert filter_keyframes([None, None], embed_batch, cfg) is None
+
+
+def test_frame_filter_apply_filters_runs_the_pipeline_on_the_dino_tower():
+    """FrameFilter.apply_filters (README alias of filter.py:317) with the random-init DINO ViT-S/16 in float32: decisions equal the oracle
+    pipeline fed with the device's own embeddings and the oracle's quality scores (the embeddings themselves: test_tower_gpu.py)."""
+    from ivr_amd.compat import FrameFilter
+    frames = _video(23, 40, 120, 160)
+    ff = FrameFilter(allow_random_init=True, compute="f32", max_batch=16)
+    cfg = dict(CFG, similarity_threshold=0.9995, transition_threshold=0.99)
+    res = ff.apply_filters([f[..., ::-1] for f in frames], cfg, bgr=True, return_details=True)
+    assert res is not None
+    scores = [Q.quality_scores(f) for f in frames]
+    # the device's embeddings of every frame (stretch resize, the tower) as the oracle pipeline's embedder
+    emb = ff.tower.encode_frames(np.stack(frames), "stretch", ff.mean, ff.std, normalize=False).cpu().numpy()
+    ref = S.keyframe_pipeline(scores, lambda i: emb[i], cfg)
+    assert ref is not None and res["kept"] == ref["kept"] and res["scenes"] == ref["scenes"]
+    kept_frames = ff.apply_filters([f[..., ::-1] for f in frames], cfg, bgr=True)
+    assert len(kept_frames) == len(ref["kept"]) and np.array_equal(kept_frames[0][..., ::-1], frames[ref["kept"][0]])
+
+
+@pytest.mark.parametrize("h,w,n", [(33, 65, 3), (32, 64, 2), (31, 63, 5), (64, 129, 2), (97, 200, 3), (2, 70, 2), (70, 2, 2)])
+def test_quality_tiles_at_ragged_sizes_and_unaligned_frames(h, w, n):
+    """Tile edges (64 x 32 tiles), widths that are not multiples of 4 (byte mark stores) and frames whose byte size is not a
+    multiple of 16 (every frame of the batch starts at a different misalignment of the 16-byte loads)."""
+    from ivr_amd.quality import frame_quality_scores
+    frames = np.concatenate([smooth_frames(h * 7 + w, n - 1, h, w), synth_frames(w, 1, h, w)])
+    for g, f in zip(frame_quality_scores(frames), frames):
+        ref = Q.quality_scores(f)
+        assert round(g["edge_density"] * h * w / 100) == round(ref["edge_density"] * h * w / 100), (g, ref)
+        assert abs(g["blur_score"] - ref["blur_score"]) <= 1e-9 * max(1.0, ref["blur_score"]), (g, ref)
+
+
+def test_quality_720p_batch_and_long_weak_chain():
+    """the hysteresis is a work list now; a 720p frame with one long weak chain hanging off a single strong spot must come
+    out with the oracle's exact edge count (the chain is as long as the frame is wide, several times)."""
+    from ivr_amd.quality import frame_quality_scores
+    h, w = 720, 1280
+    img = np.full((h, w), 100, np.uint8)
+    for r in range(20, h - 20, 40):                      # a serpentine of weak gradient
+        img[r, 20:w - 20] = 112
+        c = w - 21 if (r // 40) % 2 == 0 else 20
+        img[r:r + 40, c] = 112
+    img[20:24, 20:24] = 255                              # the only strong spot
+    chain = np.repeat(img[..., None], 3, axis=2)
+    frames = np.stack([chain, smooth_frames(9, 1, h, w)[0], synth_frames(10, 1, h, w)[0]])
+    got = frame_quality_scores(frames, canny_low=20, canny_high=300)
+    for g, f in zip(got, frames):
+        ref = Q.quality_scores(f, low=20, high=300)
+        assert round(g["edge_density"] * h * w / 100) == round(ref["edge_density"] * h * w / 100), (g, ref)
+        assert abs(g["blur_score"] - ref["blur_score"]) <= 1e-9 * max(1.0, ref["blur_score"])
+    assert got[0]["edge_density"] * h * w / 100 > 2 * (w - 40)         # far beyond the strong spot: a chain longer than the frame is wide
