@@ -58,6 +58,10 @@ int ivr_init(int device, ivr_ctx **out);
 int ivr_destroy(ivr_ctx *ctx);
 const char *ivr_last_error(ivr_ctx *ctx);       /* ctx may be NULL */
 int ivr_device_info(ivr_ctx *ctx, int *cu_count, int64_t *hbm_bytes, char *arch, int arch_len);
+/* Device scratch (ivr_preprocess intermediates, ivr_frame_quality planes, ...) is kept per stream and only grows.  A caller that
+ * retires a stream (and every graph captured on it) hands its block back with this call: it waits for the stream, frees the block
+ * and forgets the stream, so a recycled stream handle starts clean.  No-op for a stream that never used scratch. */
+int ivr_release_stream_scratch(ivr_ctx *ctx, ivr_stream stream);
 
 /* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the launch stream ---------------
  * No counterpart in the reference (its only profiler is the wall-clock PerformanceMonitor.timer,

@@ -27,7 +27,9 @@ int ivr_ctx_scratch(ivr_ctx *ctx, hipStream_t stream, size_t bytes, void **out) 
     ivr_ctx::Scratch &b = ctx->scratch[stream];
     if (bytes > b.bytes) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(stream, &cap);
+        // the legacy null stream cannot be captured - and querying it while ANOTHER thread captures in global mode would
+        // invalidate that capture
+        if (stream != nullptr) (void)hipStreamIsCapturing(stream, &cap);
         if (cap != hipStreamCaptureStatusNone)
             return ivr_fail(IVR_ERR_STATE, "scratch of %zu bytes for a stream under graph capture: run the same call once on THIS stream "
                                            "before capturing (the block is per stream and cannot be allocated during capture)", bytes);
@@ -179,6 +181,25 @@ int ivr_destroy(ivr_ctx *ctx) {
     for (void *p : ctx->retired) (void)hipFree(p);
     for (auto &kv : ctx->luts) (void)hipFree(kv.second);
     delete ctx;
+    return IVR_OK;
+}
+
+int ivr_release_stream_scratch(ivr_ctx *ctx, ivr_stream stream) {
+    IVR_REQUIRE(ctx != nullptr, "ivr_release_stream_scratch: ctx is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    void *p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->scratch.find(s);
+        if (it == ctx->scratch.end()) return IVR_OK;
+        p = it->second.ptr;
+        ctx->scratch.erase(it);
+    }
+    if (p) {
+        IVR_HIP(hipSetDevice(ctx->device));
+        IVR_HIP(hipStreamSynchronize(s));        // kernels of this stream may still use the block
+        IVR_HIP(hipFree(p));
+    }
     return IVR_OK;
 }
 

@@ -1839,6 +1839,24 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs g) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            // Key blocks of the tile's LAST images can reach past the 8 zeroed pad rows (T = 10: row 303, T = 26: 271) into the
+            // next region or stale staging bytes.  Their scores are masked below (P = 0), but 0 x Inf/NaN is NaN inside the MFMA:
+            // select zeros into the V elements of keys >= T whenever the shape can reach past row 263 (wave-uniform; never for
+            // T = 50, where (G-1) T + 63 = 263).  Element r of vt[nt][kb] is key 16 kb + 4 gl + r.
+            if ((g.G - 1) * Tn + 63 > 263) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    if (kb * 16 + 15 < Tn) continue;
+                    const int k0 = kb * 16 + gl * 4;
+                    const unsigned mlo = (k0 < Tn ? 0x0000ffffu : 0u) | (k0 + 1 < Tn ? 0xffff0000u : 0u);
+                    const unsigned mhi = (k0 + 2 < Tn ? 0x0000ffffu : 0u) | (k0 + 3 < Tn ? 0xffff0000u : 0u);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        vt[nt][kb].x &= mlo;
+                        vt[nt][kb].y &= mhi;
+                    }
+                }
+            }
         }
         f32x4 sc[4];
         float mx = -INFINITY;

@@ -38,6 +38,7 @@ _SIGS = {
     "ivr_destroy": (_i, [_p]),
     "ivr_last_error": (C.c_char_p, [_p]),
     "ivr_device_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i64), C.c_char_p, _i]),
+    "ivr_release_stream_scratch": (_i, [_p, _p]),
     "ivr_profile_enable": (_i, [_p, _i]),
     "ivr_profile_reset": (_i, [_p]),
     "ivr_profile_json": (_i, [_p, C.c_char_p, _i]),

@@ -155,6 +155,71 @@ def _load_local_checkpoint(path):
     raise FileNotFoundError(f"{path}: neither model.safetensors nor pytorch_model.bin")
 
 
+def _clip_configs_from_checkpoint(path, hf_cfg, sd):
+    """(vision TowerConfig, text TowerConfig) of a local CLIP checkpoint, from its config.json (hidden_size, patch_size, image_size,
+    num_hidden_layers, num_attention_heads, intermediate_size, projection_dim; text: the same + max_position_embeddings, vocab_size,
+    eos_token_id) and, where config.json is missing or silent, from the weight shapes.  The shape is taken from the checkpoint, not
+    guessed from the hidden width alone: clip-vit-base-patch16 and -patch32 share width 768.  Shapes the kernels do not run
+    (head_dim != 64) are refused here, by name."""
+    import dataclasses
+    v, t = dict(hf_cfg.get("vision_config") or {}), dict(hf_cfg.get("text_config") or {})
+
+    def shape(name):
+        return tuple(np.asarray(sd[name]).shape) if name in sd else None
+
+    pe = shape("vision_model.embeddings.patch_embedding.weight")            # [D, 3, P, P]
+    pos = shape("vision_model.embeddings.position_embedding.weight")         # [T, D]
+    fc1 = shape("vision_model.encoder.layers.0.mlp.fc1.weight")              # [mlp, D]
+    vproj = shape("visual_projection.weight")                                 # [proj, D]
+    width = int(v.get("hidden_size") or (pe[0] if pe else 0))
+    patch = int(v.get("patch_size") or (pe[2] if pe else 0))
+    layers = int(v.get("num_hidden_layers") or (1 + max((int(k.split(".")[3]) for k in sd if k.startswith("vision_model.encoder.layers.")),
+                                                         default=-1)))
+    mlp = int(v.get("intermediate_size") or (fc1[0] if fc1 else 0))
+    proj = int(hf_cfg.get("projection_dim") or v.get("projection_dim") or (vproj[0] if vproj else 0))
+    image = int(v.get("image_size") or (int(round((pos[0] - 1) ** 0.5)) * patch if pos and patch else 224))
+    heads = int(v.get("num_attention_heads") or (width // 64 if width else 0))
+    known = {(c[0].width, c[0].patch, c[0].layers, c[0].out_dim): c for c in CLIPFeatureExtractor.ARCH.values()}
+    supported = "supported towers: any CLIP ViT with head_dim 64, width and mlp multiples of 64 (openai/clip-vit-base-patch32, " \
+                "-base-patch16, -large-patch14, ...)"
+    if not (width and patch and layers and mlp and proj and heads) or image % patch:
+        raise ValueError(f"{path}: cannot read the vision tower's shape (hidden_size={width}, patch_size={patch}, layers={layers}, "
+                         f"intermediate_size={mlp}, projection_dim={proj}, image_size={image}) from config.json / the weights; {supported}")
+    if width != heads * 64 or width % 64 or mlp % 64 or proj % 16:
+        raise ValueError(f"{path}: vision tower {width}-wide with {heads} heads (head_dim {width // max(heads, 1)}), mlp {mlp}, projection "
+                         f"{proj} is not runnable by the HIP towers; {supported}")
+    if (width, patch, layers, proj) in known:
+        vis, txt = known[(width, patch, layers, proj)]
+    else:
+        base = C.CLIP_VIT_B32
+        vis = dataclasses.replace(base, name=f"clip-vit-{width}-p{patch}", width=width, layers=layers, heads=heads, mlp=mlp,
+                                  tokens=1 + (image // patch) ** 2, out_dim=proj, image=image, patch=patch)
+        txt = None
+    # the text tower (kept as published unless the checkpoint says otherwise)
+    tw = int(t.get("hidden_size") or (shape("text_model.embeddings.token_embedding.weight") or (0, 0))[1])
+    if tw:
+        tfc1 = shape("text_model.encoder.layers.0.mlp.fc1.weight")
+        tl = int(t.get("num_hidden_layers") or (1 + max((int(k.split(".")[3]) for k in sd if k.startswith("text_model.encoder.layers.")),
+                                                         default=-1)))
+        th = int(t.get("num_attention_heads") or tw // 64)
+        tm = int(t.get("intermediate_size") or (tfc1[0] if tfc1 else 4 * tw))
+        tt = int(t.get("max_position_embeddings") or (shape("text_model.embeddings.position_embedding.weight") or (77,))[0])
+        vocab = int(t.get("vocab_size") or (shape("text_model.embeddings.token_embedding.weight") or (49408,))[0])
+        eos = int(t.get("eos_token_id") if t.get("eos_token_id") is not None else vocab - 1)
+        if eos >= vocab or eos == 2:          # published CLIP configs carry eos_token_id = 2 although the tokenizer emits vocab - 1
+            eos = vocab - 1
+        if tw != th * 64:
+            raise ValueError(f"{path}: text tower {tw}-wide with {th} heads is not runnable by the HIP towers (head_dim must be 64)")
+        ref = txt or C.CLIP_TEXT_B32
+        cand = dataclasses.replace(ref, name=f"clip-text-{tw}", width=tw, layers=tl, heads=th, mlp=tm, tokens=tt, out_dim=proj, vocab=vocab,
+                                   eos_id=eos)
+        txt = ref if txt is not None and (ref.width, ref.layers, ref.mlp, ref.tokens, ref.out_dim, ref.vocab) == (
+            cand.width, cand.layers, cand.mlp, cand.tokens, cand.out_dim, cand.vocab) else cand
+    elif txt is None:
+        txt = C.CLIP_TEXT_B32 if proj == 512 else C.CLIP_TEXT_L14
+    return vis, txt
+
+
 class CLIPFeatureExtractor:
     """core.py:1384.  Where the weights come from, in this order:
       * `weights` / `text_weights`: canonical float32 dicts (ivr_amd.weights) or a HF state dict;
@@ -182,12 +247,7 @@ class CLIPFeatureExtractor:
             vis_cfg, txt_cfg = self.ARCH[model_path]
         elif isinstance(model_path, str) and os.path.isdir(model_path):
             local_sd, hf_cfg = _load_local_checkpoint(model_path)
-            width = int(hf_cfg.get("vision_config", {}).get("hidden_size", 0)) or int(
-                np.asarray(local_sd["vision_model.embeddings.class_embedding"]).shape[0])
-            by_width = {c[0].width: c for c in self.ARCH.values()}
-            if width not in by_width:
-                raise ValueError(f"{model_path}: vision width {width} is not one of the supported CLIP towers {sorted(by_width)}")
-            vis_cfg, txt_cfg = by_width[width]
+            vis_cfg, txt_cfg = _clip_configs_from_checkpoint(model_path, hf_cfg, local_sd)
         else:
             raise ValueError(f"unknown model_path {model_path!r}: expected one of {sorted(self.ARCH)} or a local checkpoint directory")
         self.vision_config, self.text_config = vis_cfg, txt_cfg

@@ -73,6 +73,18 @@ class StreamingSession:
         self.index.search_device(self.queries, self.k, normalize=self.normalize_queries, out=(self.D, self.I),
                                  id_base=self.sharded.id_base if self.sharded is not None else 0)
 
+    def close(self):
+        """Drop the captured graph and hand the session stream's scratch block back to the library (ivr_release_stream_scratch):
+        scratch is per stream and grow-only, so short-lived sessions would otherwise each leave a block behind until ivr_destroy."""
+        stream = getattr(self, "stream", None)
+        self.graph = None
+        if stream is not None and self.tower.device.type == "cuda":
+            from . import _ffi
+            import ctypes as C
+            _ffi.check(_ffi.load().ivr_release_stream_scratch(_ffi.context(self.tower.device.index), C.c_void_p(stream.cuda_stream)),
+                       "ivr_release_stream_scratch")
+            self.stream = None
+
     def step(self, frames=None):
         """frames: uint8 [n,h,w,3] (CUDA or pinned host) for this step, or None to reuse the buffer.  Returns (D, I)
         device tensors that the next step overwrites."""
