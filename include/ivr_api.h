@@ -220,6 +220,14 @@ int ivr_index_scan_stats(ivr_index *index, int *out /*HOST [2]*/);
 int ivr_topk_merge(ivr_ctx *ctx, const float *D_parts /*DEV*/, const int64_t *I_parts /*DEV*/, int parts,
                    int nq, int k, float *D /*DEV*/, int64_t *I /*DEV*/, ivr_stream stream);
 
+/* The same merge straight from the buffer of the ONE all-gather of the sharded search: a candidate travels as three int32 words
+ * (score bits, id low, id high), so the exchange is pack (one launch) -> all_gather_into_tensor -> merge (one launch).
+ * packed: DEV int32 [nq,k,3]; packed_parts: DEV int32 [parts,nq,k,3], parts ordered by ascending id range. */
+int ivr_topk_pack(ivr_ctx *ctx, const float *D /*DEV*/, const int64_t *I /*DEV*/, int nq, int k, int32_t *packed /*DEV*/,
+                  ivr_stream stream);
+int ivr_topk_merge_packed(ivr_ctx *ctx, const int32_t *packed_parts /*DEV*/, int parts, int nq, int k, float *D /*DEV*/,
+                          int64_t *I /*DEV*/, ivr_stream stream);
+
 /* ---- D1: near-duplicate frame filter ------------------------------------------------------------
  * Replaces the cosine_similarity(...) >= SIM_THRESHOLD loop at video_frame_filter.py:63-70.
  * emb: DEV float32 [n,d] in frame order.  keep[t] = 1 iff cos(emb[t], last kept) < threshold.

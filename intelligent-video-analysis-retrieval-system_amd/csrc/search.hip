@@ -582,7 +582,29 @@ struct SrcParts {      // shard merge: candidate p = part*k + j; ties resolve to
     }
 };
 
-enum { OUT_GROUPS = 0, OUT_DI = 1, OUT_DI_PARTS = 2 };
+struct SrcPacked {     // shard merge straight from the all-gather buffer: candidate = three int32 words (score bits, id lo, id hi)
+    const int32_t *cand;   // [parts][nq][k][3]
+    int nq, k;
+    int64_t n;             // parts * k
+    __device__ const int32_t *at(int q, int64_t p) const { return cand + (((p / k) * nq + q) * k + (p % k)) * 3; }
+    __device__ uint64_t key(int q, int64_t p) const {
+        const int32_t *c = at(q, p);
+        if (c[2] < 0) return 0;                       // id -1: unused slot
+        return ((uint64_t)ivr_f2ord(__int_as_float(c[0])) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)p);
+    }
+};
+
+enum { OUT_GROUPS = 0, OUT_DI = 1, OUT_DI_PARTS = 2, OUT_DI_PACKED = 3 };
+
+__global__ __launch_bounds__(256) void pack_candidates_kernel(const float *__restrict__ D, const int64_t *__restrict__ I, int64_t n,
+                                                              int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = I[i];
+    out[3 * i] = __float_as_int(D[i]);
+    out[3 * i + 1] = (int32_t)(uint32_t)(id & 0xffffffffll);
+    out[3 * i + 2] = (int32_t)(id >> 32);
+}
 
 constexpr int kRegKeys = 16;   // keys cached per thread: n <= 16 * 1024 is selected without re-reading global memory
 
@@ -795,6 +817,9 @@ __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(Src src, int q
                 if (OUT == OUT_DI_PARTS) {
                     const int kk = ((const SrcParts *)&src)->k, nq = ((const SrcParts *)&src)->nq;
                     id = I_parts[((int64_t)(low / kk) * nq + q) * kk + (low % kk)];
+                } else if (OUT == OUT_DI_PACKED) {
+                    const int32_t *c = ((const SrcPacked *)&src)->at(q, low);
+                    id = ((int64_t)c[2] << 32) | (uint32_t)c[1];
                 } else {
                     id = id_base + (int64_t)low;
                 }
@@ -1466,6 +1491,27 @@ int ivr_topk_merge(ivr_ctx *ctx, const float *D_parts, const int64_t *I_parts, i
     SrcParts sp{D_parts, I_parts, nq, k, (int64_t)parts * k};
     hipLaunchKernelGGL((select_topk_kernel<SrcParts, OUT_DI_PARTS>), dim3(nq), dim3(sel_threads((int64_t)parts * k)), 0, (hipStream_t)stream, sp, 0,
                        k, (int64_t)0, (uint32_t *)nullptr, D, I, I_parts);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+int ivr_topk_pack(ivr_ctx *ctx, const float *D, const int64_t *I, int nq, int k, int32_t *packed, ivr_stream stream) {
+    IVR_REQUIRE(ctx && D && I && packed, "ivr_topk_pack: NULL argument");
+    IVR_REQUIRE(nq >= 1 && k >= 1, "ivr_topk_pack: nq=%d k=%d", nq, k);
+    IVR_HIP(hipSetDevice(ctx->device));
+    const int64_t n = (int64_t)nq * k;
+    hipLaunchKernelGGL(pack_candidates_kernel, dim3((unsigned)ivr_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, D, I, n, packed);
+    IVR_LAUNCH_CHECK();
+    return IVR_OK;
+}
+
+int ivr_topk_merge_packed(ivr_ctx *ctx, const int32_t *packed_parts, int parts, int nq, int k, float *D, int64_t *I, ivr_stream stream) {
+    IVR_REQUIRE(ctx && packed_parts && D && I, "ivr_topk_merge_packed: NULL argument");
+    IVR_REQUIRE(parts >= 1 && nq >= 1 && k >= 1 && k <= IVR_MAX_K, "ivr_topk_merge_packed: parts=%d nq=%d k=%d", parts, nq, k);
+    IVR_HIP(hipSetDevice(ctx->device));
+    SrcPacked sp{packed_parts, nq, k, (int64_t)parts * k};
+    hipLaunchKernelGGL((select_topk_kernel<SrcPacked, OUT_DI_PACKED>), dim3(nq), dim3(sel_threads((int64_t)parts * k)), 0, (hipStream_t)stream, sp,
+                       0, k, (int64_t)0, (uint32_t *)nullptr, D, I, (const int64_t *)nullptr);
     IVR_LAUNCH_CHECK();
     return IVR_OK;
 }

@@ -70,6 +70,8 @@ _SIGS = {
     "ivr_index_reserve_search": (_i, [_p, _i, _i]),
     "ivr_index_search": (_i, [_p, _p, _i, _i, _i, _i64, _p, _p, _p]),
     "ivr_topk_merge": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "ivr_topk_pack": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "ivr_topk_merge_packed": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
     "ivr_rowwise_cosine": (_i, [_p, _p, _p, _i, _i, _p, _p]),
     "ivr_dedup_keep_mask": (_i, [_p, _p, _i, _i, _f, _p, _p, _p]),
     "ivr_scene_keep_mask": (_i, [_p, _p, _i, _i, _f, _i, _p, _p]),

@@ -205,3 +205,26 @@ def topk_merge(D_parts, I_parts, k=None):
                                       C.c_void_p(D.data_ptr()), C.c_void_p(I.data_ptr()), _ffi.stream_ptr()),
                    "ivr_topk_merge")
     return D, I
+
+
+def topk_pack(D, I):
+    """(D float32 [nq,k], I int64 [nq,k]) CUDA -> int32 [nq,k,3] (score bits, id lo, id hi): the wire format of the one all-gather."""
+    lib = _ffi.load()
+    nq, k = D.shape
+    out = torch.empty((nq, k, 3), dtype=torch.int32, device=D.device)
+    with torch.cuda.device(D.device):
+        _ffi.check(lib.ivr_topk_pack(_ffi.context(D.device.index), C.c_void_p(D.contiguous().data_ptr()), C.c_void_p(I.contiguous().data_ptr()),
+                                     nq, k, C.c_void_p(out.data_ptr()), _ffi.stream_ptr()), "ivr_topk_pack")
+    return out
+
+
+def topk_merge_packed(packed_parts):
+    """Merge gathered candidates int32 [parts,nq,k,3] (parts in ascending id order) -> (D [nq,k], I [nq,k])."""
+    lib = _ffi.load()
+    parts, nq, k, _ = packed_parts.shape
+    D = torch.empty((nq, k), dtype=torch.float32, device=packed_parts.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=packed_parts.device)
+    with torch.cuda.device(packed_parts.device):
+        _ffi.check(lib.ivr_topk_merge_packed(_ffi.context(packed_parts.device.index), C.c_void_p(packed_parts.data_ptr()), parts, nq, k,
+                                             C.c_void_p(D.data_ptr()), C.c_void_p(I.data_ptr()), _ffi.stream_ptr()), "ivr_topk_merge_packed")
+    return D, I

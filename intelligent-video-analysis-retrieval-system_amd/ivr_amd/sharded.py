@@ -98,6 +98,13 @@ class ShardedIndex:
         if self.world == 1:
             return D, I
         nq, k = D.shape
+        if self.merge == "device" and D.is_cuda:
+            # pack (one launch) -> the all-gather -> merge straight from the gathered buffer (one launch)
+            from .index import topk_merge_packed, topk_pack
+            cand = topk_pack(D, I)
+            gathered = torch.empty((self.world, nq, k, 3), dtype=torch.int32, device=D.device)
+            dist.all_gather_into_tensor(gathered, cand, group=self.group)
+            return topk_merge_packed(gathered)
         cand = torch.empty((nq, k, 3), dtype=torch.int32, device=D.device)
         cand[..., 0] = D.contiguous().view(torch.int32)
         cand[..., 1:] = I.contiguous().view(torch.int32).view(nq, k, 2)
@@ -106,9 +113,6 @@ class ShardedIndex:
         gathered = gathered.view(self.world, nq, k, 3)
         Dg = gathered[..., 0].contiguous().view(torch.float32)
         Ig = gathered[..., 1:].contiguous().view(torch.int64).view(self.world, nq, k)
-        if self.merge == "device" and Dg.is_cuda:
-            from .index import topk_merge
-            return topk_merge(Dg, Ig, k)
         return merge_host(Dg, Ig, k)
 
 
