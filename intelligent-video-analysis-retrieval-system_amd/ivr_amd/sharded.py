@@ -102,9 +102,9 @@ class ShardedIndex:
             # pack (one launch) -> the all-gather -> merge straight from the gathered buffer (one launch)
             from .index import topk_merge_packed, topk_pack
             cand = topk_pack(D, I)
-            gathered = torch.empty((self.world, nq, k, 3), dtype=torch.int32, device=D.device)
+            gathered = torch.empty((self.world * nq, k, 3), dtype=torch.int32, device=D.device)     # concatenated along dim 0
             dist.all_gather_into_tensor(gathered, cand, group=self.group)
-            return topk_merge_packed(gathered)
+            return topk_merge_packed(gathered.view(self.world, nq, k, 3))
         cand = torch.empty((nq, k, 3), dtype=torch.int32, device=D.device)
         cand[..., 0] = D.contiguous().view(torch.int32)
         cand[..., 1:] = I.contiguous().view(torch.int32).view(nq, k, 2)
