@@ -24,6 +24,7 @@ struct GemmArgs {
     int out8 = 0;                  // fp8 GEMM, EPI_STORE: write saturated e4m3 instead of bf16
     int wide_epi = 0;              // set by the launcher: 256 x 256 kernel may use the row-wide LDS-staged epilogue
     int reverse_m = 0;             // walk the row panels from the last to the first (see run_layers: producer / consumer order)
+    int stagger = 0;               // persistent kernel: odd slots start this many s_sleep(127) later (half a tile); set by the launcher
     int skip_mod = 0;              // EPI_RESID: rows r with r % skip_mod == 0 are left untouched (0 = none); the fp8 mode's
                                    // token-0 rows are updated by a bf16 side GEMM instead
 };

@@ -83,8 +83,14 @@ struct El<float> {
 template <bool FAST>
 __device__ __forceinline__ float act_fn(float x, int act) {
     if (act == IVR_ACT_QUICK_GELU) {                                          // x * sigmoid(1.702 x)
+        if (FAST) {
+            // exp(-1.702 x) = exp2(x * (-1.702 * log2 e)): ONE multiply in front of the raw v_exp_f32 instead of two (the fc1
+            // epilogue is VALU-bound: 128 elements per lane at ~34 issue cycles each were 10 k of a 41 k-cycle tile)
+            const float e = __builtin_amdgcn_exp2f(x * -2.4554669595930157f);
+            return x * __builtin_amdgcn_rcpf(1.0f + e);
+        }
         const float e = __expf(-1.702f * x);
-        return FAST ? x * __builtin_amdgcn_rcpf(1.0f + e) : x / (1.0f + e);
+        return x / (1.0f + e);
     }
     if (FAST) {
         // exact-GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside the bf16 / e4m3 output rounding):
@@ -101,6 +107,29 @@ __device__ __forceinline__ float act_fn(float x, int act) {
         return 0.5f * x * (1.0f + copysignf(erf_abs, x));
     }
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+
+// Four adjacent outputs at once, bf16-output epilogues: quick_gelu written on float2 vectors so that the multiplies and the add run
+// as v_pk_mul_f32 / v_pk_add_f32 (two elements per issue slot; hipcc does not pack them on its own around the transcendentals).
+// Same operations per element as act_fn<true>, so the results are identical.
+__device__ __forceinline__ void act4_fast(float (&v)[4], int act) {
+    if (act == IVR_ACT_QUICK_GELU) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t c = {-2.4554669595930157f, -2.4554669595930157f}, one = {1.0f, 1.0f};
+        f32x2_t a = {v[0], v[1]}, b = {v[2], v[3]};
+        const f32x2_t ta = a * c, tb = b * c;
+        const f32x2_t da = f32x2_t{__builtin_amdgcn_exp2f(ta.x), __builtin_amdgcn_exp2f(ta.y)} + one;
+        const f32x2_t db = f32x2_t{__builtin_amdgcn_exp2f(tb.x), __builtin_amdgcn_exp2f(tb.y)} + one;
+        a = a * f32x2_t{__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y)};
+        b = b * f32x2_t{__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y)};
+        v[0] = a.x;
+        v[1] = a.y;
+        v[2] = b.x;
+        v[3] = b.y;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = act_fn<true>(v[i], act);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -445,10 +474,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4]
             for (int nt = 0; nt < 4; ++nt) {
                 const f32x4 a = acc[nt][mt];
                 float v[4] = {a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w};
-                if (ACT >= 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = act_fn<true>(v[i], ACT);
-                }
+                if (ACT >= 0) act4_fast(v, ACT);
                 *reinterpret_cast<uint32_t *>(wb + (mt * 16 + r) * 64 + ((nt ^ ((r >> 1) & 3)) << 4) + gq * 4) =
                     ivr_pack_fp8x4(v[0], v[1], v[2], v[3]);
             }
@@ -468,10 +494,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4]
             for (int nt = 0; nt < 4; ++nt) {
                 const f32x4 a = acc[nt][mt];
                 float v[4] = {a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w};
-                if (ACT >= 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = act_fn<true>(v[i], ACT);
-                }
+                if (ACT >= 0) act4_fast(v, ACT);
                 uint2 o;
                 o.x = ivr_pack_bf16x2(v[0], v[1]);
                 o.y = ivr_pack_bf16x2(v[2], v[3]);
@@ -566,8 +589,7 @@ constexpr int DEEP_LDS = 3 * LX_BYTES + 2 * LW_BYTES;   // 160 KiB (bf16 / f32 k
 // SKIP: EPI_RESID leaves rows r % skip_mod == 0 alone (a template parameter: the runtime test cost the plain instantiation 68 bytes
 // of scratch per lane)
 template <typename T, int EPI, int ACT, bool SKIP = false>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void gemm_big_tile(const GemmArgs &g, const int vb, unsigned char *smem) {
     IVR_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -575,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
     int tm, tn;
     {
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int xcd = vb & 7, i = vb >> 3;          // vb: the tile's position in the launch order (blockIdx.x of the plain kernel)
         const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;
         if (i >= lx * NT) return;
         const int gm = g.group_m;
@@ -804,6 +826,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     IVR_STAMP(3)
 #endif
+}
+
+template <typename T, int EPI, int ACT, bool SKIP = false>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemm_big_tile<T, EPI, ACT, SKIP>(g, (int)blockIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1918,6 +1946,305 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs g) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the 256 x 256 bf16 GEMM (round 3).  s_memtime stamps of gemm_big_kernel (tools/exp_epilogue_contention.py,
+// profiles/r03h_epilogue_contention.log): a tile's prologue is 4.6 - 7.3 k cycles (fc1: 10 % of the tile), and the f32 residual
+// epilogue takes 16 k cycles with a quarter of the chip busy but 31 - 35 k with every CU in it at once - the lockstep of
+// same-length tiles makes the chip's HBM idle during K loops and saturate during epilogues.  Here one workgroup per CU walks
+// its tiles as ONE flattened sequence of K stages, exactly like scanq_kernel (search_scanq.hip):
+//   * the LDS-DMA cursors run two / one stages ahead ACROSS tile boundaries: only the first tile of a workgroup has a prologue;
+//   * the epilogues therefore may not use the LDS (the next tile's stages are live in it): the bf16 store epilogue pairs column
+//     tiles with v_permlane16_swap so that a lane holds 8 consecutive columns (16 rows x 64 B per store), the f32 residual
+//     epilogue reads / adds / writes float4 straight from the MFMA layout (16 rows x 64 B); the fragment prefetch of the next
+//     stage is deferred behind the epilogue, which frees its 48 registers for the residual rows in flight;
+//   * odd slots start half a tile late (GemmArgs.stagger), so that half the chip is in its K loop while the other half is in its
+//     epilogue - the phase persists because every tile of a launch takes the same time.
+// Tile order inside an XCD = gemm_big_kernel's (groups of group_m row panels, column tiles outermost inside a group), dealt to
+// the XCD's slots round-robin: slots that run at the same time work on the same few panels and column tiles.
+// Arithmetic per output element is gemm_big_kernel's (same K order, same epilogue expressions): results are bit-identical.
+// Measured (tools/ab_gemm_pers.py, profiles/r03i_ab_gemm_persistent.log, interleaved rounds in one process, 4,096 frames):
+//   fc1 (bf16 store + quick_gelu, K = 768) 0.990 -> 0.937 ms (-5 %), qkv 0.689 -> 0.685; patch (K = 3072: 48 stages, the prologue is
+//   nothing) 0.767 -> 0.775; the RESIDUAL sites LOSE: attn-out 0.375 -> 0.466 ms, fc2 0.908 -> 1.32 ms - the 64-byte read-modify-write
+//   straight from the MFMA layout is far slower than the 4-row x 256-byte LDS-staged one, and the staggered start changes nothing
+//   (+-1 %; also with the tile-per-workgroup body in a persistent loop: 0.445 vs 0.439 ms, both slower than the plain launch, whose
+//   dispatch order balances the uneven epilogue times dynamically).  So the launcher uses this kernel for the store epilogue with
+//   K <= 1024 only; IVR_GEMM_PERS=0 switches it off, 2 forces it wherever the shape allows (both epilogues: the parity tests).
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmArgs g) {
+    typedef unsigned short T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int MT = (g.M + LBM - 1) / LBM, NT = (g.N + LBN - 1) / LBN;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;                   // row panels of this XCD
+    const int nitems = lx * NT;
+    if (slot >= nitems) return;
+    const int count = (nitems - slot + nslots - 1) / nslots;
+    const int KT = g.K / 64;
+    const int S = count * KT;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int gm = g.group_m;
+    // item n of this workgroup = number slot + n * nslots of the XCD's tile list
+    auto locate = [&](int n, int &tm, int &tn) {
+        const unsigned i = (unsigned)(slot + n * nslots);
+        const unsigned per = (unsigned)(gm * NT), grp = i / per, within = i - grp * per;
+        const unsigned gme = (unsigned)min(gm, lx - (int)grp * gm);
+        tm = xcd + 8 * (int)(grp * gm + within % gme);
+        tn = (int)(within / gme);
+        if (g.reverse_m) tm = MT - 1 - tm;
+    };
+    // per-lane part of a DMA piece's address (row lane >> 3 of the piece, swizzled 16-byte chunk): ONE register per operand; the
+    // piece's own rows (8 * (4 wave + j)) go into the scalar offset (gemm_big_kernel keeps eight such registers)
+    const unsigned voffX = (unsigned)((lane >> 3) * g.lda) * 2u + (((lane & 7) ^ (lane >> 3)) << 4);
+    const unsigned voffW = (unsigned)((lane >> 3) * g.ldw) * 2u + (((lane & 7) ^ (lane >> 3)) << 4);
+    const unsigned prowX = (unsigned)(8 * wave * 4 * g.lda) * 2u, pstepX = (unsigned)(8 * g.lda) * 2u;
+    const unsigned prowW = (unsigned)(8 * wave * 4 * g.ldw) * 2u, pstepW = (unsigned)(8 * g.ldw) * 2u;
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.A), 0, (int)((int64_t)g.M * g.lda * 2), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * 2), 0x00020000);
+    constexpr int WBASE = 3 * LX_BYTES;
+    // DMA cursors: the next stage to issue for the row operand (X) and for the weights (W)
+    int xn = 0, xkt = 0, wcn = 0, wkt = 0;
+    unsigned sx0, sw0;
+    {
+        int tm, tn;
+        locate(0, tm, tn);
+        sx0 = (unsigned)(tm * LBM) * (unsigned)g.lda * 2u;
+        sw0 = (unsigned)(tn * LBN) * (unsigned)g.ldw * 2u;
+    }
+    auto pieceX = [&](int xs, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(smem + xs * LX_BYTES + (wave * 4 + j) * 1024), 16,
+                                                 voffX, sx0 + prowX + (unsigned)j * pstepX + (unsigned)xkt * ROWB, 0, 0);
+    };
+    auto pieceW = [&](int ws, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(smem + WBASE + ws * LW_BYTES + (wave * 4 + j) * 1024),
+                                                 16, voffW, sw0 + prowW + (unsigned)j * pstepW + (unsigned)wkt * ROWB, 0, 0);
+    };
+    auto advanceX = [&]() {
+        if (++xkt == KT) {
+            xkt = 0;
+            if (++xn < count) {
+                int tm, tn;
+                locate(xn, tm, tn);
+                sx0 = (unsigned)(tm * LBM) * (unsigned)g.lda * 2u;
+            }
+        }
+    };
+    auto advanceW = [&]() {
+        if (++wkt == KT) {
+            wkt = 0;
+            if (++wcn < count) {
+                int tm, tn;
+                locate(wcn, tm, tn);
+                sw0 = (unsigned)(tn * LBN) * (unsigned)g.ldw * 2u;
+            }
+        }
+    };
+    // fragment addresses of the first K half; the second half is the same address with chunk bit 2 flipped (^ 64): two registers
+    const unsigned f0 = (lane & 15) * ROWB + (((lane >> 4) ^ (lane & 7)) << 4);
+    const unsigned foX0 = lds0 + (wm * 128) * ROWB + f0, foW0 = lds0 + WBASE + (wn * 64) * ROWB + f0;
+    // odd slots start half a tile late: their epilogues fall into the other half's K loops
+    if (g.stagger > 0 && (slot & 1)) {
+        for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
+    f32x4 acc[4][8];   // [nt][mt]
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+#define GP_ROW(XF, WF, MT_, FIRST)                                                                                          \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[nt][MT_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                 \
+        __builtin_bit_cast(bf16x8_t, WF[nt]), __builtin_bit_cast(bf16x8_t, XF[MT_]), FIRST ? zero : acc[nt][MT_], 0, 0, 0);  \
+    __builtin_amdgcn_sched_barrier(0);
+#define GP_RD4(DST, ADDR, O0)                                                                              \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[0]) : "v"(ADDR), "n"(O0));                      \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[1]) : "v"(ADDR), "n"(O0 + 2048));               \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[2]) : "v"(ADDR), "n"(O0 + 4096));               \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[3]) : "v"(ADDR), "n"(O0 + 6144));
+#define GP_LGKM(N)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 xa0[8], wa0[4], xa1[8], wa1[4];
+    u32x4 *x0lo = xa0, *x0hi = xa0 + 4, *x1lo = xa1, *x1hi = xa1 + 4;
+    // prologue (once per workgroup): stage 0, then X(1), W(1), X(2)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pieceX(0, j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pieceW(0, j);
+    advanceX();
+    advanceW();
+    if (S > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pieceX(1, j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pieceW(1, j);
+        advanceX();
+        advanceW();
+    }
+    if (S > 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pieceX(2, j);
+        advanceX();
+    }
+    if (S > 2) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    else if (S > 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    GP_RD4(wa0, foW0, 0)
+    GP_RD4(x0lo, foX0, 0)
+    GP_RD4(x0hi, foX0, 8192)
+
+    int xs = 0, cn = 0, ckt = 0;
+    bool drain = false;                 // the previous stage ended with an epilogue: its global loads / stores count in vmcnt too
+    for (int s = 0; s < S; ++s) {
+        const int xs1 = xs == 2 ? 0 : xs + 1, xs2 = xs1 == 2 ? 0 : xs1 + 1;
+        const unsigned xoff = xs * LX_BYTES, woff = (s & 1) * LW_BYTES, nxoff = xs1 * LX_BYTES, nwoff = ((s + 1) & 1) * LW_BYTES;
+        const bool tail = s >= 1 && s + 2 < S;
+        const bool morew = s + 2 < S, morex = s + 3 < S, next = s + 1 < S;
+        const bool last = ckt == KT - 1;              // the item's last stage: its epilogue follows
+        const unsigned wa = (foW0 ^ 64u) + woff, xa = (foX0 ^ 64u) + xoff, nwa = foW0 + nwoff, nxa = foX0 + nxoff;
+#define GP_SET0(FIRST)                                                                                     \
+        GP_LGKM(4)                                                                                         \
+        GP_ROW(xa0, wa0, 0, FIRST)                                                                         \
+        if (tail) pieceX(xs2, 2);                                                                          \
+        GP_ROW(xa0, wa0, 1, FIRST)                                                                         \
+        GP_RD4(wa1, wa, 0)                                                                                 \
+        GP_ROW(xa0, wa0, 2, FIRST)                                                                         \
+        if (tail) pieceX(xs2, 3);                                                                          \
+        GP_ROW(xa0, wa0, 3, FIRST)                                                                         \
+        GP_RD4(x1lo, xa, 0)                                                                                \
+        GP_LGKM(8)                                                                                         \
+        GP_ROW(xa0, wa0, 4, FIRST)                                                                         \
+        GP_ROW(xa0, wa0, 5, FIRST)                                                                         \
+        GP_RD4(x1hi, xa, 8192)                                                                             \
+        GP_ROW(xa0, wa0, 6, FIRST)                                                                         \
+        GP_ROW(xa0, wa0, 7, FIRST)
+        if (ckt == 0) {
+            GP_SET0(true)
+        } else {
+            GP_SET0(false)
+        }
+#undef GP_SET0
+        GP_LGKM(0)
+        if (s >= 1) advanceX();
+        if (next) {
+            if (s + 2 < S && !drain) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        drain = false;
+        GP_ROW(xa1, wa1, 0, false)
+        if (morew) pieceW(s & 1, 0);
+        GP_ROW(xa1, wa1, 1, false)
+        if (next) { GP_RD4(wa0, nwa, 0) }
+        if (morew) pieceW(s & 1, 1);
+        GP_ROW(xa1, wa1, 2, false)
+        if (morew) pieceW(s & 1, 2);
+        GP_ROW(xa1, wa1, 3, false)
+        if (next) { GP_RD4(x0lo, nxa, 0) }
+        if (morew) pieceW(s & 1, 3);
+        GP_ROW(xa1, wa1, 4, false)
+        if (morex) pieceX(xs, 0);
+        GP_ROW(xa1, wa1, 5, false)
+        if (next) { GP_RD4(x0hi, nxa, 8192) }
+        GP_ROW(xa1, wa1, 6, false)
+        if (morex) pieceX(xs, 1);
+        GP_ROW(xa1, wa1, 7, false)
+        if (morew) advanceW();
+        xs = xs1;
+        if (!last) {
+            ++ckt;
+            continue;
+        }
+        // ---- tile finished: epilogue straight from the accumulators (no LDS: the next tile's stages are live in it) ----
+        ckt = 0;
+        int tm, tn;
+        locate(cn, tm, tn);
+        ++cn;
+        // the lane-dependent addressing of the epilogue is derived from an opaque copy of the lane id: the compiler would otherwise
+        // hoist it out of the stage loop and hold ~40 more registers across the MFMA code (259 spilled registers)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int r = lane_e & 15, h = lane_e >> 4;
+        const int row0 = tm * LBM + wm * 128, col0 = tn * LBN + wn * 64;
+        if (col0 < g.N) {                                   // N is a multiple of 64: a wave's block is all in or all out
+            float4 bv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                bv[nt] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + col0 + nt * 16 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (EPI == EPI_STORE) {
+                // pair the column tiles (nt, nt+1): after the swaps lane (r, h) holds 8 consecutive columns of tile nt + (h & 1)
+                T *outp = reinterpret_cast<T *>(g.out) + col0 + (h & 1) * 16 + (h >> 1) * 8;
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int row = row0 + mt * 16 + r;
+#pragma unroll
+                    for (int np = 0; np < 2; ++np) {
+                        uint32_t pk[2][2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const f32x4 a = acc[2 * np + e][mt];
+                            const float4 b = bv[2 * np + e];
+                            float v[4] = {a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w};
+                            if (ACT >= 0) act4_fast(v, ACT);
+                            pk[e][0] = ivr_pack_bf16x2(v[0], v[1]);
+                            pk[e][1] = ivr_pack_bf16x2(v[2], v[3]);
+                        }
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                        if (row < g.M) *reinterpret_cast<uint4 *>(outp + (int64_t)row * g.ldo + np * 32) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    }
+                }
+            } else {
+                float *resp = g.resid + col0 + 4 * h;
+#pragma unroll
+                for (int mh = 0; mh < 4; ++mh) {            // two row tiles of residual in flight (32 registers: the next stage's
+                    float4 rv[2][4];                        // fragments, already being read, hold 48)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int row = min(row0 + (mh * 2 + mt) * 16 + r, g.M - 1);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) rv[mt][nt] = *reinterpret_cast<const float4 *>(resp + (int64_t)row * g.ldr + nt * 16);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int row = row0 + (mh * 2 + mt) * 16 + r;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const f32x4 a = acc[nt][mh * 2 + mt];
+                            float4 o = rv[mt][nt];
+                            o.x += a[0] + bv[nt].x;
+                            o.y += a[1] + bv[nt].y;
+                            o.z += a[2] + bv[nt].z;
+                            o.w += a[3] + bv[nt].w;
+                            if (row < g.M) *reinterpret_cast<float4 *>(resp + (int64_t)row * g.ldr + nt * 16) = o;
+                        }
+                    }
+                }
+            }
+        }
+        drain = true;
+    }
+    GP_LGKM(0)
+#undef GP_ROW
+#undef GP_RD4
+#undef GP_LGKM
+}
+
+static int device_cu_count() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    int &c = cus[dev];
+    if (c == 0) {
+        hipDeviceProp_t prop;
+        c = hipGetDeviceProperties(&prop, dev) == hipSuccess ? std::max(8, prop.multiProcessorCount) : 256;
+    }
+    return c;
+}
+
 template <typename T, int EPI, int ACT>
 int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
@@ -1938,6 +2265,22 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
         else if (EPI == EPI_RESID)
             ga.wide_epi = wide_env && bias_ok && g.N % 64 == 0 && g.ldr % 4 == 0 && reinterpret_cast<uintptr_t>(g.resid) % 16 == 0;
         const int grid = 8 * ((MT + 7) / 8) * NT;
+        // persistent form (gemm_pers_kernel): bf16 store / residual epilogues under the row-wide epilogue's alignment conditions,
+        // problems of at least two tiles per CU.  IVR_GEMM_PERS=0 keeps the one-tile-per-workgroup kernel (A/B runs, parity tests).
+        const int pers = env_int("IVR_GEMM_PERS", 1);          // 2: wherever the shape allows (tests), whatever the size
+        if (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_RESID) && ga.wide_epi && !g.skip_mod && pers &&
+            (pers >= 2 || (EPI == EPI_STORE && g.K <= 1024 && MT * NT >= 2 * device_cu_count()))) {
+            constexpr int PE = EPI == EPI_RESID ? EPI_RESID : EPI_STORE;      // (the other epilogues never get here)
+            if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(gemm_pers_kernel<PE, ACT>), DEEP_LDS)) return rc;
+            // half a tile of head start for the even slots when the epilogue is the HBM-bound one: (K loop + epilogue) / 2 in units
+            // of s_sleep(127) = 8,128 cycles; the bf16 store epilogue is bound per CU (activation + packing), no stagger
+            const int auto_stagger = EPI == EPI_RESID ? ((g.K / 64) * 2560 + 18000) / 2 / 8128 : 0;
+            const int st = env_int("IVR_GEMM_STAGGER", -1);
+            ga.stagger = st >= 0 ? st : auto_stagger;
+            hipLaunchKernelGGL((gemm_pers_kernel<PE, ACT>), dim3(device_cu_count() / 8 * 8), dim3(512), DEEP_LDS, s, ga);
+            IVR_LAUNCH_CHECK();
+            return IVR_OK;
+        }
         if (EPI == EPI_RESID && g.skip_mod) {
             constexpr bool kSkip = EPI == EPI_RESID;
             if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(gemm_big_kernel<T, EPI, ACT, kSkip>), DEEP_LDS)) return rc;

@@ -253,9 +253,14 @@ def test_config4_workload_fp8_rows_mixed_queries():
         queries = torch.cat([emb[n_rows:], tq])
         D, I = idx.search_device(queries, k)
         rows_h, q_h = emb[:n_rows].cpu().numpy(), queries.cpu().numpy()
-        Dr, Ir = S.flat_ip_search(rows_h, q_h, k, dtype=np.float64)
-        assert np.array_equal(I.cpu().numpy(), Ir), compute               # ids exact over the same rows
-        assert np.abs(D.cpu().numpy() - Dr).max() < 1e-5
+        Dr, Ir = S.flat_ip_search(rows_h, q_h, k + 1, dtype=np.float64)
+        # ids exact over the same rows - outside float32 near-ties: random-init towers put all 64 rows within ~1e-2 of each other, so
+        # neighbours in the ranking can be closer than float32 scoring resolves (the exact float32 path orders them the same way)
+        gap = np.minimum(np.abs(np.diff(Dr, axis=1, prepend=np.inf))[:, :k], np.abs(np.diff(Dr, axis=1))[:, :k])
+        firm = gap > 1e-6
+        assert np.array_equal(I.cpu().numpy()[firm], Ir[:, :k][firm]), compute
+        assert firm.mean() > 0.9
+        assert np.abs(D.cpu().numpy() - Dr[:, :k]).max() < 1e-5
         results[compute] = (rows_h, q_h, I.cpu().numpy())
     ref = np.concatenate([V.vision_forward(vis, wv, P.preprocess(frames[i:i + 16], "identity", C.CLIP_MEAN, C.CLIP_STD))
                           for i in range(0, len(frames), 16)])

@@ -16,12 +16,14 @@ def _ref(x, w, b, act):
     return y
 
 
-@pytest.fixture(params=["auto", "128x128", "256x256", "256x256-narrow"])
+@pytest.fixture(params=["auto", "128x128", "256x256", "256x256-narrow", "256x256-persistent"])
 def kernel(request, monkeypatch):
-    """The launcher picks the 256 x 256 kernel only for problems that fill the chip; the tests drive BOTH kernels (and both
-    epilogues of the large one) with every shape through the A/B switches the launcher reads on each call."""
+    """The launcher picks the 256 x 256 kernels only for problems that fill the chip; the tests drive ALL of them (both epilogues of
+    the one-tile-per-workgroup kernel, and the persistent kernel of round 3 wherever its alignment conditions hold) with every shape
+    through the A/B switches the launcher reads on each call."""
     if request.param != "auto":
         monkeypatch.setenv("IVR_GEMM", "0" if request.param == "128x128" else "4")
+    monkeypatch.setenv("IVR_GEMM_PERS", "2" if request.param == "256x256-persistent" else "0")
     if request.param == "256x256-narrow":
         monkeypatch.setenv("IVR_GEMM_WIDE_EPI", "0")
     return request.param
@@ -108,3 +110,43 @@ def test_row_operand_beyond_2gib_runs_in_slabs():
     r = torch.zeros((M, N), dtype=torch.float32, device="cuda")
     linear(x, w, b, epilogue=EPI_RESID, resid=r)
     assert (r[rows] - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(40_000, 768, 768, -1), (11_003, 3072, 768, 0), (70_001, 768, 3072, -1), (131_072, 256, 128, 1),
+                                       (300, 768, 768, -1)])
+def test_persistent_kernel_is_bit_identical_to_the_tile_per_workgroup_kernel(M, N, K, act, monkeypatch):
+    """gemm_pers_kernel walks several tiles per workgroup as one flattened stage sequence (DMA look-ahead across tile boundaries,
+    LDS-free epilogues, staggered start): same K order and the same epilogue expressions as gemm_big_kernel, so store and residual
+    outputs must be BIT-identical, ragged last panels and both zigzag directions included; small integers catch any layout slip."""
+    from ivr_amd.linear import EPI_RESID, linear
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = (torch.randn((M, K), generator=g, device="cuda") * 0.7).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    r0 = torch.randn((M, N), generator=g, device="cuda")
+    outs = {}
+    for mode, stagger in (("0", "0"), ("2", "0"), ("2", "3")):
+        monkeypatch.setenv("IVR_GEMM", "4")
+        monkeypatch.setenv("IVR_GEMM_PERS", mode)
+        monkeypatch.setenv("IVR_GEMM_STAGGER", stagger)
+        y = linear(x, w, b, act=act)
+        r = r0.clone()
+        linear(x, w, b, epilogue=EPI_RESID, resid=r)
+        outs[(mode, stagger)] = (y, r)
+    for key in (("2", "0"), ("2", "3")):
+        assert torch.equal(outs[key][0], outs[("0", "0")][0]), key
+        assert torch.equal(outs[key][1], outs[("0", "0")][1]), key
+    rows = torch.tensor([0, 255, 256, M // 2, M - 1], device="cuda")
+    ref = x[rows].float() @ w.float().T + b
+    if act == 0:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    elif act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    assert (outs[("2", "3")][0][rows].float() - ref).abs().max() <= 1.2e-2 * max(1.0, float(ref.abs().max()))
+    xi = torch.randint(-3, 4, (M, K), generator=g, device="cuda").to(torch.bfloat16)
+    wi = torch.randint(-3, 4, (N, K), generator=g, device="cuda").to(torch.bfloat16)
+    monkeypatch.setenv("IVR_GEMM_PERS", "2")
+    ri = torch.zeros((M, N), device="cuda")
+    linear(xi, wi, None, epilogue=EPI_RESID, resid=ri)
+    pick = torch.tensor([0, 1, 257, M // 3, M - 1], device="cuda")
+    assert torch.equal(ri[pick], xi[pick].float() @ wi.float().T)
