@@ -33,7 +33,18 @@ for (m, n, k) in shapes:
     for it in range(iters if m < 20000 else max(8, iters // 8)):
         with torch.cuda.stream(side):
             junk_b.copy_(junk_a, non_blocking=True)
+        os.environ["IVR_GEMM_PERS"] = "0"
         outs = {"store": linear(x, w, b, act=0), "resid": linear(x, w, b, epilogue=EPI_RESID, resid=r0.clone())}
+        if n % 64 == 0:
+            # the persistent kernel (round 3: flattened stage sequence across tiles, LDS-free epilogues, staggered start) must give the
+            # tile-per-workgroup kernel's bits on every launch
+            os.environ["IVR_GEMM_PERS"] = "2"
+            os.environ["IVR_GEMM_STAGGER"] = str(it % 4)
+            outs["store_persistent"] = linear(x, w, b, act=0)
+            outs["resid_persistent"] = linear(x, w, b, epilogue=EPI_RESID, resid=r0.clone())
+            os.environ["IVR_GEMM_PERS"] = "0"
+            if it == 0:
+                assert torch.equal(outs["store_persistent"], outs["store"]) and torch.equal(outs["resid_persistent"], outs["resid"])
         if k % 128 == 0 and n % 64 == 0:
             outs["fp8"] = linear_fp8(x8, w8, ws, b)
             outs["fp8_resid"] = linear_fp8(x8, w8, ws, b, epilogue=EPI_RESID, resid=r0.clone())
@@ -46,6 +57,28 @@ for (m, n, k) in shapes:
                 print(f"MISMATCH {name} M={m} N={n} K={k} iteration {it}: {(o.float() - ref[name].float()).abs().max().item()}")
     torch.cuda.synchronize()
     print(f"gemm M={m} N={n} K={k}: {it + 1} launches x {len(outs)} variants reproduced" if not bad else f"gemm M={m} N={n} K={k}: mismatches so far {bad}")
+os.environ.pop("IVR_GEMM_PERS", None)
+os.environ.pop("IVR_GEMM_STAGGER", None)
+# the large-batch candidate scan (search_scanq.hip: persistent workgroups, DMA cursors across work items, counted vmcnt)
+from ivr_amd.index import FlatIPIndex  # noqa: E402
+for (rows, d, nq, k) in ((300_001, 512, 300, 10), (120_000, 768, 1000, 5), (70_000, 96, 65, 50)):
+    g = torch.Generator(device="cuda").manual_seed(rows + nq)
+    idx = FlatIPIndex(d, capacity=rows)
+    idx.add(torch.randn((rows, d), generator=g, device="cuda"), normalize=True)
+    q = torch.randn((nq, d), generator=g, device="cuda")
+    ref = None
+    for it in range(max(10, iters // 3)):
+        with torch.cuda.stream(side):
+            junk_b.copy_(junk_a, non_blocking=True)
+        D, I = idx.search_device(q, k, normalize=True)
+        if ref is None:
+            ref = (D.clone(), I.clone())
+        elif not (torch.equal(D, ref[0]) and torch.equal(I, ref[1])):
+            bad += 1
+            print(f"MISMATCH large-batch search rows={rows} d={d} nq={nq} iteration {it}")
+    torch.cuda.synchronize()
+    print(f"large-batch search {rows} x {d}, {nq} queries: {it + 1} launches reproduced")
+    idx.close()
 for name, batch in (("l14", 24), ("dino", 64), ("b32", 256)):
     cfg = {"b32": C.CLIP_VIT_B32, "l14": C.CLIP_VIT_L14, "dino": C.DINO_VIT_S16}[name]
     tw = Tower(cfg, make_weights(cfg, 3), max_batch=batch)
