@@ -477,12 +477,25 @@ struct ListArgs {
 // TILES: the selection holds 16-row tiles instead of 64-row groups (large-batch scan): one wave per (query, selected tile),
 // cand[q][j*16 + row].  qmap (list-driven exact pass): query q of this launch is the list's q-th entry, qmap[q] in the tiled
 // query buffer; waves past *qcount exit.
+// Pruning of the large-batch re-score (TILES only): the selection is sorted by approximate tile maximum, so with t_k = the k-th
+// selected tile's approximate maximum there are k tiles that each hold a row with exact score >= t_k - e; a tile whose approximate
+// maximum is below t_k - 2e holds only rows with exact score < t_k - e and cannot reach the top k.  Such tiles are not fetched
+// (their candidate slots are written as absent); e is the verification's bound, from the same measured residuals.
+struct PruneArgs {
+    const float *tmax = nullptr;          // non-NULL enables pruning
+    int64_t tstride = 0;
+    int k = 0;
+    const float *qnorm = nullptr, *qdelta = nullptr;
+    const unsigned int *maxnorm_bits = nullptr, *maxdelta_bits = nullptr;
+    float acc_eps = 0.f;
+};
+
 template <bool TILES>
 __global__ __launch_bounds__(256) void rescore_groups_kernel(const float *__restrict__ data,
                                                              const float *__restrict__ qtiled, int dp4,
                                                              int64_t ntotal, const uint32_t *__restrict__ sel,
                                                              int sel_stride, int ksel, int nq, uint64_t *__restrict__ cand,
-                                                             const int *__restrict__ skip, ListArgs la) {
+                                                             const int *__restrict__ skip, ListArgs la, PruneArgs pr = PruneArgs()) {
     constexpr int kRows = TILES ? 16 : kGroupRows, kSplit = TILES ? 1 : 4;
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -498,6 +511,18 @@ __global__ __launch_bounds__(256) void rescore_groups_kernel(const float *__rest
     if (g == 0xFFFFFFFFu) {   // fewer groups than k
         if (lane < 16) out[lane] = 0;
         return;
+    }
+    if (TILES && pr.tmax && j >= pr.k) {          // the first k tiles are always re-scored
+        const uint32_t gk = sel[(int64_t)q * sel_stride + pr.k - 1];
+        if (gk != 0xFFFFFFFFu) {
+            const float rmax = __uint_as_float(*pr.maxnorm_bits), qn = pr.qnorm[q], qd = pr.qdelta[q];
+            const float e = 1.01f * ((qn + qd) * __uint_as_float(*pr.maxdelta_bits) + qd * rmax + pr.acc_eps * qn * rmax);
+            // NaN / inf bounds compare false: nothing is pruned then
+            if (pr.tmax[(int64_t)q * pr.tstride + g] < pr.tmax[(int64_t)q * pr.tstride + gk] - 2.f * e) {
+                if (lane < 16) out[lane] = 0;
+                return;
+            }
+        }
     }
     const int per_tile = dp4 * 16, kchunks = dp4 >> 2;
     const float4 *b = reinterpret_cast<const float4 *>(qtiled) + (int64_t)(qs >> 4) * per_tile + lane;
@@ -890,6 +915,7 @@ struct ivr_index {
     int *okq = nullptr;              // DEV [kBigChunk] verification result per query, [4] failure count, [kBigChunk] failed queries
     bool last_big = false;           // the last search went through the large-batch scan
     bool bigq = true;                // IVR_SCAN_BIGQ=0 keeps every batch on the 64-query chunks (A/B switch, read at creation)
+    bool prune = true;               // IVR_SCAN_PRUNE=0: the large-batch re-score fetches all kp selected tiles (A/B switch)
 };
 
 namespace {
@@ -1132,8 +1158,19 @@ int search_big(ivr_index *x, int q0, int nqc, int k, int64_t id_base, float *D, 
     {
         const int64_t waves = (int64_t)nqc * kp;
         IvrProf prof("rescore_tiles", s, (double)waves * 16 * x->dp * 4, true);
+        PruneArgs pr;
+        if (x->prune) {
+            pr.tmax = x->tmax;
+            pr.tstride = tstride;
+            pr.k = k;
+            pr.qnorm = x->qnorm + q0;
+            pr.qdelta = x->qdelta + q0;
+            pr.maxnorm_bits = x->maxnorm;
+            pr.maxdelta_bits = x->maxdelta;
+            pr.acc_eps = (float)x->dp * 1.2e-7f;
+        }
         hipLaunchKernelGGL(rescore_groups_kernel<true>, dim3((unsigned)ivr_ceil_div(waves, 4)), dim3(256), 0, s, x->data, qtile, x->dp4, x->ntotal,
-                           x->sel, ksel2, kp, nqc, x->cand, (const int *)nullptr, ListArgs());
+                           x->sel, ksel2, kp, nqc, x->cand, (const int *)nullptr, ListArgs(), pr);
         IVR_LAUNCH_CHECK();
     }
     {
@@ -1215,6 +1252,8 @@ int ivr_index_create(ivr_ctx *ctx, int d, int64_t capacity_rows, ivr_index **out
         x->scan16 = !(e && e[0] == '0');   // LDS per 16-query tile (hi + lo) = 64 dp bytes, the same as the float32 scan's
         const char *b = getenv("IVR_SCAN_BIGQ");
         x->bigq = !(b && b[0] == '0');
+        const char *pr = getenv("IVR_SCAN_PRUNE");
+        x->prune = !(pr && pr[0] == '0');
     }
     // an even number of pieces per tile: the large-batch scan steps K by two pieces; an odd tail piece stays all zero on both sides
     x->pieces = (int)ivr_round_up(x->pieces, 2);

@@ -178,3 +178,20 @@ def test_baseline_config3_shard_full_size():
     assert np.abs(D.cpu().numpy()[sample] - Dr).max() < 1e-5
     print(f"configs[2] shard: {redone} of {nq} queries redone exactly")
     assert redone <= 20
+
+
+def test_pruned_rescore_equals_the_full_rescore():
+    """The large-batch re-score skips selected tiles whose approximate maximum is more than twice the error bound below the k-th
+    selected tile's (they cannot hold a top-k row): same D and I as with every selected tile fetched (IVR_SCAN_PRUNE=0), on rows
+    where most tiles are pruned (Gaussian) and on rows where none can be (a tight cluster)."""
+    rng = np.random.default_rng(21)
+    d, N = 384, 160_000
+    base = rng.standard_normal(d).astype(np.float32)
+    for X in (rng.standard_normal((N, d)).astype(np.float32), (base[None, :] + 3e-3 * rng.standard_normal((N, d))).astype(np.float32)):
+        X = S.normalize_rows_core(X).astype(np.float32)
+        Q = np.concatenate([rng.standard_normal((150, d)).astype(np.float32), X[:50] + 1e-3 * rng.standard_normal((50, d)).astype(np.float32)])
+        a, b = _index_with({}, d, X), _index_with({"IVR_SCAN_PRUNE": "0"}, d, X)
+        for k in (1, 10, 40):
+            Da, Ia = a.search_device(Q, k, normalize=True)
+            Db, Ib = b.search_device(Q, k, normalize=True)
+            assert torch.equal(Ia, Ib) and torch.equal(Da, Db)
