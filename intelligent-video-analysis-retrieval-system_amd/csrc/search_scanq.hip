@@ -193,7 +193,6 @@ __global__ __launch_bounds__(512, 2) void scanq_kernel(ScanQArgs g) {
 
     int xs = 0;            // row slot of stage s = s % 3
     int ckt = 0;           // K stage of the item being computed (the item itself: pc)
-    bool stores_pending = false;     // the previous stage ended with an epilogue: its global stores count in vmcnt too
     for (int s = 0; s < S; ++s) {
         const int xs1 = xs == 2 ? 0 : xs + 1, xs2 = xs1 == 2 ? 0 : xs1 + 1;
         const unsigned xoff = xs * SQ_SLOT, woff = (s & 1) * SQ_SLOT, nxoff = xs1 * SQ_SLOT, nwoff = ((s + 1) & 1) * SQ_SLOT;
@@ -227,12 +226,13 @@ __global__ __launch_bounds__(512, 2) void scanq_kernel(ScanQArgs g) {
         SQ_LGKM(0)                      // this wave has read everything it needs from the stage's buffers
         if (s >= 1) advanceX();         // the row cursor now names stage s + 3
         if (next) {
-            // X(s+1) and W(s+1) must have landed; the four youngest pieces in flight are X(s+2), which may stay - unless the
-            // epilogue's stores are among the outstanding operations (loads and stores are not retired in a common order)
-            if (s + 2 < S && !stores_pending) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            // X(s+1) and W(s+1) must have landed; the four youngest LOADS in flight are X(s+2), which may stay.  The global stores of an
+            // item's epilogue count in vmcnt too and are not retired in a common order with the loads, but they can only make this wait
+            // longer, never release it early: with at most 4 operations outstanding, an outstanding piece of stage s+1 would imply
+            // its four younger loads (in order among themselves) outstanding as well - five.
+            if (s + 2 < S) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        stores_pending = false;
         SQ_ROW(xa1, wa1, 0, false)
         if (morew) pieceW(s & 1, 0);
         SQ_ROW(xa1, wa1, 1, false)
@@ -286,7 +286,6 @@ __global__ __launch_bounds__(512, 2) void scanq_kernel(ScanQArgs g) {
             b = sq_fold32(b, b);
             if (h == 0) g.bmax[q * g.bstride + (row0 >> 7)] = b;
         }
-        stores_pending = true;
     }
 #undef SQ_ROW
 #undef SQ_RD4

@@ -2096,7 +2096,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmArgs g) {
     GP_RD4(x0hi, foX0, 8192)
 
     int xs = 0, cn = 0, ckt = 0;
-    bool drain = false;                 // the previous stage ended with an epilogue: its global loads / stores count in vmcnt too
     for (int s = 0; s < S; ++s) {
         const int xs1 = xs == 2 ? 0 : xs + 1, xs2 = xs1 == 2 ? 0 : xs1 + 1;
         const unsigned xoff = xs * LX_BYTES, woff = (s & 1) * LW_BYTES, nxoff = xs1 * LX_BYTES, nwoff = ((s + 1) & 1) * LW_BYTES;
@@ -2129,10 +2128,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmArgs g) {
         GP_LGKM(0)
         if (s >= 1) advanceX();
         if (next) {
-            if (s + 2 < S && !drain) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            // (an epilogue's global stores count in vmcnt too; they can only lengthen this wait, never release it early: scanq_kernel)
+            if (s + 2 < S) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        drain = false;
         GP_ROW(xa1, wa1, 0, false)
         if (morew) pieceW(s & 1, 0);
         GP_ROW(xa1, wa1, 1, false)
@@ -2223,7 +2222,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmArgs g) {
                 }
             }
         }
-        drain = true;
     }
     GP_LGKM(0)
 #undef GP_ROW
