@@ -33,7 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PMC_NAME = {"scan_groupmax": "scan_groupmax_kernel<1>", "scan16_groupmax": "scan16_groupmax_kernel<1>", "preprocess_emit": "emit_vec_kernel<bf16, 32>"}
-PMC_FILE = "r02_pmc_traffic.json"   # the committed PMC passes `traffic` is read from (tools/pmc_aggregate.py)
+PMC_FILE = "r03_pmc_traffic.json"   # the committed PMC passes `traffic` is read from (tools/pmc_aggregate.py)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA
 
@@ -530,8 +530,8 @@ def main():
                              "note": "50 searches back to back outside the timed region, no per-kernel events",
                              "per_launch_us_with_events": search_kernels_us},
             "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": gemm_tf / mfma_peak,
-                         "traffic": traffic(*[k for k in pmc if k.startswith(("gemm_big_kernel<bf16", "gemm_kernel<bf16", "qkv_attn_kernel<bf16"))]),
-                         "kernel": ("gemm_big_kernel<bf16> / qkv_attn_kernel<bf16> (QKV projection fused with attention) / gemm_kernel<bf16>" if args.compute == "bf16" else "gemm_big8_kernel (e4m3 sites) + the bf16 GEMMs of the other sites, patch embedding and projection")
+                         "traffic": traffic(*[k for k in pmc if k.startswith(("gemm_big_kernel<bf16", "gemm_pers_kernel", "gemm_kernel<bf16", "qkv_attn_kernel<bf16"))]),
+                         "kernel": ("gemm_big_kernel<bf16> / gemm_pers_kernel (fc1) / qkv_attn_kernel<bf16> (QKV projection fused with attention) / gemm_kernel<bf16>" if args.compute == "bf16" else "gemm_big8_kernel (e4m3 sites) + the bf16 GEMMs of the other sites, patch embedding and projection")
                                    + " (all tower GEMM launches of the timed region)",
                          "avg_launch_ms": gemm_ms / max(1, gemm_launches), "launches": int(gemm_launches),
                          "flop_per_launch": gemm_flop / max(1, gemm_launches),
