@@ -1947,6 +1947,342 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent form of qkv_attn_kernel (round 3): one workgroup per CU walks its (row tile, head) items; the LDS is laid out so that
+// stage 0 of the K-loop ring (bottom 56 KiB) and the Q | K | V images (top 99 KiB) are disjoint, and the NEXT item's stage 0 is
+// fetched by LDS-DMA during the attention phase of the current one: a tile's 4.2 k-cycle prologue (11 % of its 37.9 k cycles, stamps
+// of round 2) becomes the landing time of stage 1 behind an already resident stage 0.  Everything else - K loop, accumulators ->
+// images, attention - is qkv_attn_kernel's code operation for operation, so the output is bit-identical to it (and to the unfused
+// path): tests/test_fused_qkv_attention_gpu.py runs both.  IVR_QKV_PERS=0 keeps the one-tile-per-workgroup kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int QP_LDS = 160 * 1024;
+
+template <typename TOut>
+__global__ __launch_bounds__(512, 2) void qkv_attn_pers_kernel(QkvAttnArgs g) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef unsigned short T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int RT = g.G * g.T;                                  // rows per tile
+    const int MT = (g.M + RT - 1) / RT, NT = g.heads;
+    // persistent: one workgroup per CU walks items slot, slot + nslots, ... of its XCD's tile list (the order of qkv_attn_kernel)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int lx = MT > xcd ? (MT - xcd + 7) >> 3 : 0;
+    const int nitems = lx * NT;
+    if (slot >= nitems) return;
+    const int count = (nitems - slot + nslots - 1) / nslots;
+    auto locate = [&](int n, int &tm_, int &h_) {
+        const int i = slot + n * nslots;
+        const int gm = g.group_m;
+        const int per = gm * NT, grp = i / per, within = i - grp * per;
+        const int gme = min(gm, lx - grp * gm);
+        tm_ = xcd + 8 * (grp * gm + within % gme);
+        h_ = within / gme;
+        if (g.reverse) tm_ = MT - 1 - tm_;
+    };
+    const int KT = g.D / 64;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // DMA pieces of 1 KiB (8 rows x 128 B): 32 of X, 24 of W per stage; wave w issues X pieces 4w..4w+3 and W pieces 3w..3w+2.
+    // W piece p covers rows 8p..8p+7 of the 192-row head tile: third p >> 3 (q, k, v), rows h*64 + 8*(p & 7) of that third.
+    unsigned voffX[4], voffW;
+    {
+        const int c = (lane & 7) ^ (lane >> 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) voffX[j] = (unsigned)((8 * (wave * 4 + j) + (lane >> 3)) * g.D) * 2u + c * 16;
+        voffW = (unsigned)((lane >> 3) * g.D) * 2u + c * 16;
+    }
+    // scalar offsets of an item's operands: X rows of its tile, W rows (q | k | v of its head) of this wave's three pieces
+    auto item_offsets = [&](int tm_, int h_, unsigned &sx, unsigned (&sw)[3]) {
+        sx = (unsigned)(tm_ * RT) * (unsigned)g.D * 2u;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = wave * 3 + j;
+            sw[j] = (unsigned)(((p >> 3) * g.D + h_ * 64 + 8 * (p & 7)) * g.D) * 2u;
+        }
+    };
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.X), 0, (int)((int64_t)g.M * g.D * 2), 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)3 * g.D * g.D * 2), 0x00020000);
+    // LDS (160 KiB), laid out so that stage 0 of the ring (X slot 0 + W slot 0 = the bottom 56 KiB) is disjoint from the Q | K | V
+    // images (the top 99 KiB): the NEXT item's stage 0 is fetched while the attention phase of the current one reads the images.
+    auto xbase = [](int xs) { return xs == 0 ? 0 : xs == 1 ? 57344 : 90112; };         // X slots: 0, 56 K, 88 K (32 KiB each)
+    auto wbase = [](int b) { return b ? 122880 : 32768; };                              // W slots: 32 K, 120 K (24 KiB each)
+    constexpr int IMG = 62464;                                                           // images: 61 K .. 160 K
+    auto piece = [&](unsigned sx, const unsigned (&sw)[3], int kt, int xs, int j) {      // j < 4: X piece (slot xs); 4..6: W piece (slot kt & 1)
+        const unsigned adv = (unsigned)kt * ROWB;
+        if (j < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void *)(smem + xbase(xs) + (wave * 4 + j) * 1024), 16,
+                                                     voffX[j], sx + adv, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(smem + wbase(kt & 1) + (wave * 3 + j - 4) * 1024),
+                                                     16, voffW, sw[j - 4] + adv, 0, 0);
+    };
+    unsigned foX[2], foW[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const unsigned f = (lane & 15) * ROWB + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+        foX[kk] = lds0 + (wm * 128) * ROWB + f;
+        foW[kk] = lds0 + (wn * 48) * ROWB + f;
+    }
+
+    int tm, h;
+    locate(0, tm, h);
+    unsigned sx0, swW[3];
+    item_offsets(tm, h, sx0, swW);
+#define QA_ROW(XF, WF, MTI)                                                                                \
+    _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) mma_chunk<T>(WF[nt], XF[MTI], acc[nt][MTI]);          \
+    __builtin_amdgcn_sched_barrier(0);
+#define QA_RD4(DST, ADDR, O0)                                                                              \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[0]) : "v"(ADDR), "n"(O0));                      \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[1]) : "v"(ADDR), "n"(O0 + 2048));               \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[2]) : "v"(ADDR), "n"(O0 + 4096));               \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[3]) : "v"(ADDR), "n"(O0 + 6144));
+#define QA_RD3(DST, ADDR)                                                                                  \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(DST[0]) : "v"(ADDR));                                         \
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(DST[1]) : "v"(ADDR));                             \
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(DST[2]) : "v"(ADDR));
+#define QA_LGKM(N)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 xa0[8], wa0[3], xa1[8], wa1[3];
+    u32x4 *x0lo = xa0, *x0hi = xa0 + 4, *x1lo = xa1, *x1hi = xa1 + 4;
+    // stage 0 of the first item; every later item finds its stage 0 fetched during the previous item's attention phase
+#pragma unroll
+    for (int j = 0; j < 7; ++j) piece(sx0, swW, 0, 0, j);
+  for (int n = 0; n < count; ++n) {
+    const int m0 = tm * RT;
+    f32x4 acc[3][8];   // [nt][mt]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bq[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int col = wn * 48 + nt * 16 + 4 * (lane >> 4);
+        bq[nt] = *reinterpret_cast<const float4 *>(g.bias + (col >> 6) * g.D + h * 64 + (col & 63));
+    }
+    // stage 1 and X(2), then wait for stage 0: the 11 pieces just issued are the youngest LOADS in flight and may stay (the stores of
+    // the previous attention phase count in vmcnt too, but can only lengthen the wait: scanq_kernel)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) piece(sx0, swW, 1, 1, j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) piece(sx0, swW, 2, 2, j);
+    asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory");
+    QA_RD3(wa0, foW[0] + wbase(0))
+    QA_RD4(x0lo, foX[0] + xbase(0), 0)
+    QA_RD4(x0hi, foX[0] + xbase(0), 8192)
+    int xs = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int xs1 = xs == 2 ? 0 : xs + 1;
+        const unsigned xoff = xbase(xs), woff = wbase(kt & 1), nxoff = xbase(xs1), nwoff = wbase((kt + 1) & 1);
+        const bool tail = kt >= 1 && kt + 2 < KT;
+        const bool morew = kt + 2 < KT, morex = kt + 3 < KT, next = kt + 1 < KT;
+        const unsigned wa = foW[1] + woff, xa = foX[1] + xoff, nwa = foW[0] + nwoff, nxa = foX[0] + nxoff;
+        QA_LGKM(4)                      // W + first four X fragments of set 0
+        QA_ROW(xa0, wa0, 0)
+        if (tail) piece(sx0, swW, kt + 2, xs1 == 2 ? 0 : xs1 + 1, 2);
+        QA_ROW(xa0, wa0, 1)
+        QA_RD3(wa1, wa)
+        QA_ROW(xa0, wa0, 2)
+        if (tail) piece(sx0, swW, kt + 2, xs1 == 2 ? 0 : xs1 + 1, 3);
+        QA_ROW(xa0, wa0, 3)
+        QA_RD4(x1lo, xa, 0)
+        QA_LGKM(7)                      // all of set 0
+        QA_ROW(xa0, wa0, 4)
+        QA_ROW(xa0, wa0, 5)
+        QA_RD4(x1hi, xa, 8192)
+        QA_ROW(xa0, wa0, 6)
+        QA_ROW(xa0, wa0, 7)
+        QA_LGKM(0)
+        if (next) {
+            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        QA_ROW(xa1, wa1, 0)
+        if (morew) piece(sx0, swW, kt + 2, 0, 4);
+        QA_ROW(xa1, wa1, 1)
+        if (next) { QA_RD3(wa0, nwa) }
+        if (morew) piece(sx0, swW, kt + 2, 0, 5);
+        QA_ROW(xa1, wa1, 2)
+        if (morew) piece(sx0, swW, kt + 2, 0, 6);
+        QA_ROW(xa1, wa1, 3)
+        if (next) { QA_RD4(x0lo, nxa, 0) }
+        QA_ROW(xa1, wa1, 4)
+        if (morex) piece(sx0, swW, kt + 3, xs, 0);
+        QA_ROW(xa1, wa1, 5)
+        if (next) { QA_RD4(x0hi, nxa, 8192) }
+        QA_ROW(xa1, wa1, 6)
+        if (morex) piece(sx0, swW, kt + 3, xs, 1);
+        QA_ROW(xa1, wa1, 7)
+        xs = xs1;
+    }
+    QA_LGKM(0)
+#undef QA_ROW
+#undef QA_RD4
+#undef QA_RD3
+#undef QA_LGKM
+    __builtin_amdgcn_s_barrier();                             // every wave has read its last fragments: the LDS is free
+
+    // ---- accumulators + bias -> bf16 Q | K | V images in LDS
+    unsigned char *const qreg = smem + IMG, *const kreg = smem + IMG + QA_REGION, *const vreg = smem + IMG + 2 * QA_REGION;
+    {
+        const int r = lane & 15, gq = lane >> 4;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int col = wn * 48 + nt * 16 + 4 * gq;       // 0..191: region col >> 6, head dim col & 63
+            const int reg3 = col >> 6, dh = col & 63, ch = dh >> 3;
+            const float4 bv = bq[nt];
+            unsigned char *base = smem + IMG + reg3 * QA_REGION + (dh & 7) * 2;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int m = wm * 128 + mt * 16 + r;
+                const f32x4 a = acc[nt][mt];
+                uint2 o;
+                o.x = ivr_pack_bf16x2(a[0] + bv.x, a[1] + bv.y);
+                o.y = ivr_pack_bf16x2(a[2] + bv.z, a[3] + bv.w);
+                const unsigned pos = reg3 == 2 ? (unsigned)((((ch >> 1) ^ ((m >> 1) & 3)) << 5) | ((ch & 1) << 4))
+                                               : (unsigned)((ch ^ (m & 7)) << 4);
+                *reinterpret_cast<uint2 *>(base + m * ROWB + pos) = o;
+            }
+        }
+        // rows 256..263 behind the K and V images: key blocks of the tile's last image may reach them (masked scores, P = 0)
+        if (tid < 128) *reinterpret_cast<uint4 *>((tid < 64 ? kreg : vreg) + 256 * ROWB + (tid & 63) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    // the next item's stage 0 goes into the bottom 56 KiB (nobody reads the ring any more) while the attention below reads the images
+    const int h_cur = h;
+    if (n + 1 < count) {
+        locate(n + 1, tm, h);
+        item_offsets(tm, h, sx0, swW);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) piece(sx0, swW, 0, 0, j);
+    }
+
+    // ---- attention: units (image, 16-query tile) dealt round-robin to the waves
+    const int Tn = g.T, nqt = (Tn + 15) >> 4, units = g.G * nqt;
+    const int gl = lane >> 4, c = lane & 15;
+    constexpr float L2E = 1.4426950408889634f;
+    for (int u = wave; u < units; u += 8) {
+        const int img = u / nqt, qt = u - img * nqt;
+        const int R0 = img * Tn;                                // first tile row of the image
+        if (m0 + R0 >= g.M) continue;                           // image past the end of the batch (last panel)
+        const int q = qt * 16 + c;
+        // All LDS reads of the unit go out together - Q fragments (B operand of S^T: row R0 + q, chunks 4 ks + gl), K fragments
+        // (A operand: rows R0 + 16 kt + c) and the sixteen transposed V^T pieces, which do not depend on the softmax - and are
+        // waited for once: issued one dependent group at a time the unit was a chain of ten LDS round trips.
+        uint4 qf[2], kf[2][4];
+        uint2 vt[4][4];                                         // [dh tile nt][16-key block]
+        {
+            const int rq = R0 + q;
+            const unsigned qa = (unsigned)(size_t)qreg + rq * ROWB, qx = rq & 7;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) asm volatile("ds_read_b128 %0, %1" : "=v"(qf[ks]) : "v"(qa + (((4 * ks + gl) ^ qx) << 4)));
+            // the four key tiles are 16 rows = 2048 bytes apart and share (row & 7)
+            const int rk = R0 + c;
+            const unsigned ka = (unsigned)(size_t)kreg + rk * ROWB, kx = rk & 7;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned a0 = ka + (((4 * ks + gl) ^ kx) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(kf[ks][0]) : "v"(a0));
+                asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(kf[ks][1]) : "v"(a0));
+                asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(kf[ks][2]) : "v"(a0));
+                asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(kf[ks][3]) : "v"(a0));
+            }
+            // V^T: this lane addresses key row 4 gl + (c >> 2) of a 16-key block, 8 bytes (c & 3) of the 32-byte segment nt
+            const int vrow = R0 + 4 * gl + (c >> 2);
+            const unsigned vbase = (unsigned)(size_t)vreg + (unsigned)vrow * ROWB + (c & 3) * 8;
+            const int xr = (vrow >> 1) & 3;                      // key blocks start 16 rows apart: (row >> 1) & 3 is the same in all four
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const unsigned va = vbase + ((nt ^ xr) << 5);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[nt][0]) : "v"(va));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(vt[nt][1]) : "v"(va));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(vt[nt][2]) : "v"(va));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(vt[nt][3]) : "v"(va));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // Key blocks of the tile's LAST images can reach past the 8 zeroed pad rows (T = 10: row 303, T = 26: 271) into the
+            // next region or stale staging bytes.  Their scores are masked below (P = 0), but 0 x Inf/NaN is NaN inside the MFMA:
+            // select zeros into the V elements of keys >= T whenever the shape can reach past row 263 (wave-uniform; never for
+            // T = 50, where (G-1) T + 63 = 263).  Element r of vt[nt][kb] is key 16 kb + 4 gl + r.
+            if ((g.G - 1) * Tn + 63 > 263) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    if (kb * 16 + 15 < Tn) continue;
+                    const int k0 = kb * 16 + gl * 4;
+                    const unsigned mlo = (k0 < Tn ? 0x0000ffffu : 0u) | (k0 + 1 < Tn ? 0xffff0000u : 0u);
+                    const unsigned mhi = (k0 + 2 < Tn ? 0x0000ffffu : 0u) | (k0 + 3 < Tn ? 0xffff0000u : 0u);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        vt[nt][kb].x &= mlo;
+                        vt[nt][kb].y &= mhi;
+                    }
+                }
+            }
+        }
+        f32x4 sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[0][kt]), __builtin_bit_cast(bf16x8_t, qf[0]), a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[1][kt]), __builtin_bit_cast(bf16x8_t, qf[1]), a, 0, 0, 0);
+            if (kt * 16 + 15 >= Tn) {             // wave-uniform: only a tile that reaches past the sequence needs the mask
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + gl * 4 + r >= Tn) a[r] = -INFINITY;
+            }
+            mx = vmax3(mx, a[0], a[1]);
+            mx = vmax3(mx, a[2], a[3]);
+            sc[kt] = a;
+        }
+        mx = quad_max(mx);                    // finite: key 0 is visible to every query
+        const float mb = -mx * L2E;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], L2E, mb));      // masked (-inf) -> 0
+                sc[kt][r] = pv;
+                sum += pv;
+            }
+        sum = quad_sum(sum);
+        uint4 pf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            pf[ks].x = ivr_pack_bf16x2(sc[2 * ks][0], sc[2 * ks][1]);
+            pf[ks].y = ivr_pack_bf16x2(sc[2 * ks][2], sc[2 * ks][3]);
+            pf[ks].z = ivr_pack_bf16x2(sc[2 * ks + 1][0], sc[2 * ks + 1][1]);
+            pf[ks].w = ivr_pack_bf16x2(sc[2 * ks + 1][2], sc[2 * ks + 1][3]);
+        }
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        const int64_t grow = (int64_t)m0 + R0 + q;
+        TOut *op = reinterpret_cast<TOut *>(g.att) + grow * g.D + h_cur * 64 + gl * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 vf = make_uint4(vt[nt][2 * ks].x, vt[nt][2 * ks].y, vt[nt][2 * ks + 1].x, vt[nt][2 * ks + 1].y);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[ks]), o, 0, 0, 0);
+            }
+            if (q < Tn && grow < g.M) {
+                const float v[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+                El<TOut>::store4(op + nt * 16, v);
+            }
+        }
+    }
+    if (n + 1 < count) __syncthreads();                         // every wave is done with the images: the ring may take stage 1 and X(2)
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // Persistent form of the 256 x 256 bf16 GEMM (round 3).  s_memtime stamps of gemm_big_kernel (tools/exp_epilogue_contention.py,
 // profiles/r03h_epilogue_contention.log): a tile's prologue is 4.6 - 7.3 k cycles (fc1: 10 % of the tile), and the f32 residual
 // epilogue takes 16 k cycles with a quarter of the chip busy but 31 - 35 k with every CU in it at once - the lockstep of
@@ -2448,6 +2784,19 @@ int ivr_launch_qkv_attention(const void *xn, const void *w, const float *bias, v
     const int grid = 8 * ((MT + 7) / 8) * heads;
     // FLOP: the projection (2 M 3D D) and the attention products (4 T^2 64 per image and head)
     IvrProf prof("gemm_qkv_attention", s, 2.0 * M * 3.0 * D * D + 4.0 * n * heads * (double)T * T * 64);
+    const int qpers = env_int("IVR_QKV_PERS", 1);           // 0: never, 2: always (tests), default: from two tiles per CU on
+    if (qpers == 2 || (qpers == 1 && (int64_t)MT * heads >= 2 * device_cu_count())) {
+        const int pgrid = device_cu_count() / 8 * 8;
+        if (out_fp8) {
+            if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(qkv_attn_pers_kernel<unsigned char>), QP_LDS)) return rc;
+            hipLaunchKernelGGL(qkv_attn_pers_kernel<unsigned char>, dim3(pgrid), dim3(512), QP_LDS, s, g);
+        } else {
+            if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(qkv_attn_pers_kernel<unsigned short>), QP_LDS)) return rc;
+            hipLaunchKernelGGL(qkv_attn_pers_kernel<unsigned short>, dim3(pgrid), dim3(512), QP_LDS, s, g);
+        }
+        IVR_LAUNCH_CHECK();
+        return IVR_OK;
+    }
     if (out_fp8) {
         if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(qkv_attn_kernel<unsigned char>), QA_LDS)) return rc;
         hipLaunchKernelGGL(qkv_attn_kernel<unsigned char>, dim3(grid), dim3(512), QA_LDS, s, g);
