@@ -32,7 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PMC_NAME = {"scan_groupmax": "scan_groupmax_kernel<1>", "scan16_groupmax": "scan16_groupmax_kernel<1>", "preprocess_emit": "emit_vec_kernel<bf16, 32>"}
+PMC_NAME = {"scan_groupmax": "scan_groupmax_kernel<1>", "scan16_groupmax": "scan16_ring_kernel<16>", "preprocess_emit": "emit_vec_kernel<bf16, 32>"}
 PMC_FILE = "r03_pmc_traffic.json"   # the committed PMC passes `traffic` is read from (tools/pmc_aggregate.py)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA

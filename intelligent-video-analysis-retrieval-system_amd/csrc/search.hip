@@ -440,6 +440,99 @@ __global__ __launch_bounds__(512) void scan16_groupmax_kernel(const uint4 *__res
     }
 }
 
+// The same candidate pass for at most 16 queries (QT = 1: the 10-query search of BASELINE configs[1] and of the streaming step), with
+// the index streamed through an LDS-DMA ring instead of through registers.  The register version keeps 8 KiB per wave in flight and
+// runs at 5.0 TB/s; HBM wants several times that outstanding.  Here every wave owns a ring of PIECES slots of 1 KiB (= one 16-row tile
+// of the bf16 copy): piece kb of the next tile is requested (buffer_load ... lds, no registers, no address arithmetic per lane) as soon
+// as piece kb of the current tile has been consumed, so a whole tile per wave = PIECES KiB x 8 waves per workgroup stays in flight.
+// The query fragments (hi + lo) live in registers (2 x PIECES x 4 VGPRs), the LDS holds nothing but the rings; a wave reads only what
+// it requested itself, so its own counted vmcnt orders every read (no workgroup barrier anywhere in the loop).  MFMA sequence per
+// accumulator = scan16_groupmax_kernel<1>'s (hi then lo, ascending K), so the group maxima are bit-identical to it.
+template <int PIECES>
+__global__ __launch_bounds__(512) void scan16_ring_kernel(const uint4 *__restrict__ data16, const uint4 *__restrict__ qhi,
+                                                          const uint4 *__restrict__ qlo, int64_t ngroups, int64_t ntotal,
+                                                          float *__restrict__ gmax, int64_t mstride) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x >> 6;
+    unsigned char *ring = ring_all + wave * PIECES * 1024;
+    const unsigned ring_lds = (unsigned)(size_t)ring + lane * 16;
+    u32x4_t bh[PIECES], bl[PIECES];
+#pragma unroll
+    for (int kb = 0; kb < PIECES; ++kb) {
+        const uint4 h = qhi[kb * 64 + lane], l = qlo[kb * 64 + lane];
+        bh[kb] = u32x4_t{h.x, h.y, h.z, h.w};
+        bl[kb] = u32x4_t{l.x, l.y, l.z, l.w};
+    }
+    const int64_t g0 = (int64_t)blockIdx.x * nw + wave, gstep = (int64_t)gridDim.x * nw;
+    if (g0 >= ngroups) return;
+    constexpr unsigned kGroupBytes = 4u * PIECES * 1024u;
+    const unsigned voff = (unsigned)lane * 16u;
+    // one buffer descriptor per 64-row group (64-bit base, 32-bit offsets inside the group); no lambda here: a lambda returning the
+    // descriptor type inside a kernel TEMPLATE makes hipcc drop the host-side instantiation silently (undefined kernel stub at load)
+#define IVR_GROUP_RSRC(G)                                                                                                      \
+    __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(data16)) + (G) * (int64_t)kGroupBytes, 0, \
+                                      (int)kGroupBytes, 0x00020000)
+    // prologue: tile 0 of the first group
+    {
+        const auto rs0 = IVR_GROUP_RSRC(g0);
+#pragma unroll
+        for (int kb = 0; kb < PIECES; ++kb)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void *)(ring + kb * 1024), 16, voff, (unsigned)kb * 1024u, 0,
+                                                     0);
+    }
+    for (int64_t g = g0; g < ngroups; g += gstep) {
+        const bool more = g + gstep < ngroups;
+        const auto rs = IVR_GROUP_RSRC(g);
+        const auto rs_next = IVR_GROUP_RSRC(more ? g + gstep : g);
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < PIECES; ++kb) {
+                // the oldest request in flight is this slot's.  In the steady state PIECES are outstanding (slots kb .. of this tile, slots
+                // .. kb-1 of the next), so all but the PIECES - 1 youngest must have landed; in the wave's very last tile nothing is
+                // requested any more and the count falls: that tile is waited for as a whole.  (The one gmax store per group counts in
+                // vmcnt too; it can only lengthen these waits: loads retire in order among themselves.)
+                if (t == 3 && !more) {
+                    if (kb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the whole last tile, once
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES - 1) : "memory");
+                }
+                u32x4_t a;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a) : "v"(ring_lds + (unsigned)kb * 1024u) : "memory");
+                // the slot is free again: request the same piece of the next tile (of this group, or of the wave's next group)
+                if (t < 3)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(ring + kb * 1024), 16, voff,
+                                                             (unsigned)((t + 1) * PIECES + kb) * 1024u, 0, 0);
+                else if (more)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void *)(ring + kb * 1024), 16, voff,
+                                                             (unsigned)kb * 1024u, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bh[kb]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bl[kb]), acc[t], 0, 0, 0);
+            }
+        }
+        const bool partial = (g + 1) * kGroupRows > ntotal;   // wave-uniform: only the last group
+        float m = -FLT_MAX;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sc = acc[t][r];
+                if (partial && g * kGroupRows + t * 16 + (lane >> 4) * 4 + r >= ntotal) sc = -FLT_MAX;
+                m = fmaxf(m, sc);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (lane < 16) gmax[(int64_t)lane * mstride + g] = m;
+    }
+#undef IVR_GROUP_RSRC
+}
+
 // Verification of the bf16 candidate scan, done by the final selection of each query (select_topk_kernel<SrcKeys, OUT_DI>): does
 // the (kp+1)-th approximate group maximum + error bound stay strictly below the k-th exact score?  ok[q] = 1 keeps the fast
 // result; otherwise the query's tile is flagged for the exact pass.  tile_flag[0..3] is reset by the group selection launched
@@ -916,6 +1009,7 @@ struct ivr_index {
     bool last_big = false;           // the last search went through the large-batch scan
     bool bigq = true;                // IVR_SCAN_BIGQ=0 keeps every batch on the 64-query chunks (A/B switch, read at creation)
     bool prune = true;               // IVR_SCAN_PRUNE=0: the large-batch re-score fetches all kp selected tiles (A/B switch)
+    bool ring = true;                // IVR_SCAN_RING=0: the <= 16-query candidate scan streams the index through registers (A/B switch)
 };
 
 namespace {
@@ -1098,6 +1192,19 @@ void launch_scan16(ivr_index *x, int64_t tile0, int64_t ngroups, int64_t mstride
                        x->q16lo + tile0 * x->pieces * 64, x->pieces, ngroups, x->ntotal, x->gmax, mstride);
 }
 
+// at most 16 queries and a piece count the ring kernel is built for: stream the index through the LDS-DMA rings
+template <int PIECES>
+void launch_scan16_ring(ivr_index *x, int64_t tile0, int64_t ngroups, int64_t mstride, hipStream_t s) {
+    const int threads = 512, nw = threads / 64;
+    const size_t lds = (size_t)nw * PIECES * 1024;
+    // one workgroup per CU (its 8 rings already keep PIECES x 8 KiB in flight); groups are dealt round-robin to the waves of the grid
+    int64_t grid = std::max<int64_t>(1, std::min<int64_t>(ivr_ceil_div(ngroups, nw), (int64_t)x->ctx->cu_count * (lds <= 64 * 1024 ? 2 : 1)));
+    (void)ivr_func_max_lds(reinterpret_cast<const void *>(scan16_ring_kernel<PIECES>), (int)lds);
+    IvrProf prof("scan16_groupmax", s, (double)x->ntotal * x->pieces * 64 + (double)2 * x->pieces * 1024 + (double)ngroups * 16 * 4);
+    hipLaunchKernelGGL(scan16_ring_kernel<PIECES>, dim3((unsigned)grid), dim3(threads), lds, s, x->data16, x->q16hi + tile0 * x->pieces * 64,
+                       x->q16lo + tile0 * x->pieces * 64, ngroups, x->ntotal, x->gmax, mstride);
+}
+
 template <int QT>
 void launch_scan_list(ivr_index *x, const float *qt, int64_t ngroups, int64_t mstride, float *gmax, const int *nlist, const int *list,
                       hipStream_t s) {
@@ -1254,6 +1361,8 @@ int ivr_index_create(ivr_ctx *ctx, int d, int64_t capacity_rows, ivr_index **out
         x->bigq = !(b && b[0] == '0');
         const char *pr = getenv("IVR_SCAN_PRUNE");
         x->prune = !(pr && pr[0] == '0');
+        const char *rg = getenv("IVR_SCAN_RING");
+        x->ring = !(rg && rg[0] == '0');
     }
     // an even number of pieces per tile: the large-batch scan steps K by two pieces; an odd tail piece stays all zero on both sides
     x->pieces = (int)ivr_round_up(x->pieces, 2);
@@ -1456,7 +1565,12 @@ int ivr_index_search(ivr_index *x, const float *q, int nq, int k, int normalize_
         }
         x->last_nqc = nqc;
         switch (qt) {
-            case 1: launch_scan16<1>(x, q0 / 16, ngroups, mstride, s); break;
+            case 1:
+                if (x->ring && x->pieces == 16) launch_scan16_ring<16>(x, q0 / 16, ngroups, mstride, s);
+                else if (x->ring && x->pieces == 12) launch_scan16_ring<12>(x, q0 / 16, ngroups, mstride, s);
+                else if (x->ring && x->pieces == 8) launch_scan16_ring<8>(x, q0 / 16, ngroups, mstride, s);
+                else launch_scan16<1>(x, q0 / 16, ngroups, mstride, s);
+                break;
             case 2: launch_scan16<2>(x, q0 / 16, ngroups, mstride, s); break;
             case 3: launch_scan16<3>(x, q0 / 16, ngroups, mstride, s); break;
             default: launch_scan16<4>(x, q0 / 16, ngroups, mstride, s); break;

@@ -139,3 +139,30 @@ def test_randomised_cross_check_against_exact_scan():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_search.py"), "8", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("d", [250, 384, 512])
+def test_ring_scan_is_bit_identical_to_the_register_scan(d):
+    """Round 3: for at most 16 queries the bf16 candidate scan streams the index through per-wave LDS-DMA rings (scan16_ring_kernel:
+    PIECES = 8 / 12 / 16) instead of through registers - same MFMA sequence, so the same group maxima, hence the same D and I as with
+    IVR_SCAN_RING=0; ragged row counts (partial last group, fewer groups than waves), 1 .. 16 queries, ring overwrites."""
+    import os
+    from ivr_amd.index import FlatIPIndex
+    rng = np.random.default_rng(d)
+    for N in (70_001, 9_000):
+        X = rng.standard_normal((N, d)).astype(np.float32)
+        a = FlatIPIndex(d, capacity=N)
+        os.environ["IVR_SCAN_RING"] = "0"
+        try:
+            b = FlatIPIndex(d, capacity=N)
+        finally:
+            del os.environ["IVR_SCAN_RING"]
+        a.add(X, normalize=True)
+        b.add(X, normalize=True)
+        for nq, k in ((1, 1), (10, 10), (16, 50)):
+            Q = rng.standard_normal((nq, d)).astype(np.float32)
+            Da, Ia = a.search_device(Q, k, normalize=True)
+            Db, Ib = b.search_device(Q, k, normalize=True)
+            assert torch.equal(Ia, Ib) and torch.equal(Da, Db), (N, nq, k)
+        if N == 70_001:
+            _check(a, a.reconstruct_n(0, N), rng.standard_normal((10, d)).astype(np.float32), 10)
