@@ -61,7 +61,9 @@ os.environ.pop("IVR_GEMM_PERS", None)
 os.environ.pop("IVR_GEMM_STAGGER", None)
 # the large-batch candidate scan (search_scanq.hip: persistent workgroups, DMA cursors across work items, counted vmcnt)
 from ivr_amd.index import FlatIPIndex  # noqa: E402
-for (rows, d, nq, k) in ((300_001, 512, 300, 10), (120_000, 768, 1000, 5), (70_000, 96, 65, 50)):
+# ... and the small-batch scan through per-wave LDS-DMA rings (scan16_ring_kernel: at most 16 queries, d <= 512)
+for (rows, d, nq, k) in ((300_001, 512, 300, 10), (120_000, 768, 1000, 5), (70_000, 96, 65, 50), (1_000_003, 512, 10, 10), (200_000, 384, 16, 5),
+                         (90_001, 250, 1, 1)):
     g = torch.Generator(device="cuda").manual_seed(rows + nq)
     idx = FlatIPIndex(d, capacity=rows)
     idx.add(torch.randn((rows, d), generator=g, device="cuda"), normalize=True)
@@ -75,9 +77,9 @@ for (rows, d, nq, k) in ((300_001, 512, 300, 10), (120_000, 768, 1000, 5), (70_0
             ref = (D.clone(), I.clone())
         elif not (torch.equal(D, ref[0]) and torch.equal(I, ref[1])):
             bad += 1
-            print(f"MISMATCH large-batch search rows={rows} d={d} nq={nq} iteration {it}")
+            print(f"MISMATCH search rows={rows} d={d} nq={nq} iteration {it}")
     torch.cuda.synchronize()
-    print(f"large-batch search {rows} x {d}, {nq} queries: {it + 1} launches reproduced")
+    print(f"{'large-batch' if nq > 64 else 'ring-scan'} search {rows} x {d}, {nq} queries: {it + 1} launches reproduced")
     idx.close()
 for name, batch in (("l14", 24), ("dino", 64), ("b32", 256)):
     cfg = {"b32": C.CLIP_VIT_B32, "l14": C.CLIP_VIT_L14, "dino": C.DINO_VIT_S16}[name]
