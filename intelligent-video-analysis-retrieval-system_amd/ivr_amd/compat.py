@@ -621,7 +621,7 @@ class UnifiedIndex:
         self.faiss_index = None
         self.metadata_list: List[Dict[str, Any]] = []
         self.metadata_cache: Dict[int, Dict[str, Any]] = {}
-        self.vectors = None
+        self._vectors = None
         self.index_file = None
 
     def __enter__(self):
@@ -707,7 +707,10 @@ class UnifiedIndex:
 
     def _install(self, V, metas, path):
         with self.lock:
-            self.vectors = V
+            # no second host copy of the rows: `.vectors` (a reference attribute) is rebuilt from the device index on first access
+            # (host copy + fp32 tiles + bf16 copy were 2.5x the rows, 17 GB at the reference's 2.2M x 768)
+            self._vectors = None
+            self._nvectors = int(len(V))
             self.metadata_list = metas
             self.metadata_cache = {}
             if self.faiss_index is not None:
@@ -719,12 +722,20 @@ class UnifiedIndex:
             self.index_file = path
             self.is_loaded = True
 
+    @property
+    def vectors(self):
+        """The stored rows as a host array [n,d] (unified_index.py keeps them in its HDF5 dataset): read back from the device index
+        on first access - L2-normalised there (unified_index.py:1776 normalises before adding) - and cached until the next build."""
+        if self._vectors is None and self.faiss_index is not None and self.is_loaded:
+            self._vectors = self.faiss_index.reconstruct_n(0, self.faiss_index.ntotal) if self.faiss_index.ntotal else np.zeros((0, 1), np.float32)
+        return self._vectors
+
     def load_unified_index(self, index_file):
         path = index_file if index_file.endswith(".npz") else index_file + ".npz"
         z = np.load(path, allow_pickle=False)
         metas = json.loads(bytes(z["metadata"]).decode())
         self._install(z["vectors"], metas, path)
-        return {"vectors_count": len(self.vectors), "metadata_count": len(metas), "index_file": path}
+        return {"vectors_count": self._nvectors, "metadata_count": len(metas), "index_file": path}
 
     def _get_metadata_cached(self, idx):
         idx = int(idx)
