@@ -530,8 +530,8 @@ def main():
                              "note": "50 searches back to back outside the timed region, no per-kernel events",
                              "per_launch_us_with_events": search_kernels_us},
             "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": gemm_tf / mfma_peak,
-                         "traffic": traffic(*[k for k in pmc if k.startswith(("gemm_big_kernel<bf16", "gemm_pers_kernel", "gemm_kernel<bf16", "qkv_attn_kernel<bf16"))]),
-                         "kernel": ("gemm_big_kernel<bf16> / gemm_pers_kernel (fc1) / qkv_attn_kernel<bf16> (QKV projection fused with attention) / gemm_kernel<bf16>" if args.compute == "bf16" else "gemm_big8_kernel (e4m3 sites) + the bf16 GEMMs of the other sites, patch embedding and projection")
+                         "traffic": traffic(*[k for k in pmc if k.startswith(("gemm_big_kernel<bf16", "gemm_pers_kernel", "gemm_kernel<bf16", "qkv_attn_kernel<bf16", "qkv_attn_pers_kernel<bf16"))]),
+                         "kernel": ("gemm_big_kernel<bf16> / gemm_pers_kernel (fc1) / qkv_attn_pers_kernel<bf16> (QKV projection fused with attention) / gemm_kernel<bf16>" if args.compute == "bf16" else "gemm_big8_kernel (e4m3 sites) + the bf16 GEMMs of the other sites, patch embedding and projection")
                                    + " (all tower GEMM launches of the timed region)",
                          "avg_launch_ms": gemm_ms / max(1, gemm_launches), "launches": int(gemm_launches),
                          "flop_per_launch": gemm_flop / max(1, gemm_launches),
