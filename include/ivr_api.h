@@ -259,7 +259,8 @@ int ivr_rowwise_cosine(ivr_ctx *ctx, const float *a /*DEV*/, const float *b /*DE
  * cv2.Canny(gray, low, high) edge pixels) for a batch of decoded frames.  frames: DEV uint8 [n,h,w,3] (bgr = 1: cv2.imread
  * order, 0: RGB).  lap_sums: DEV int64 [n,2] = (sum, sum of squares) of the integer Laplacian response over the frame - the
  * variance is (s2 - s1*s1/N) / N with N = h*w, finished in float64 by the caller; edge_count: DEV int64 [n] = number of Canny
- * edge pixels (edge density = 100 * count / N).  Scratch (5 bytes per pixel) lives in the context, per stream. */
+ * edge pixels (edge density = 100 * count / N).  w <= 16384.  Scratch (two bit planes = 2 bits per pixel, rows padded to 64 pixels, + 16 B per
+ * 64 x 32 tile) lives in the context, per stream. */
 int64_t ivr_frame_quality_scratch_bytes(int n, int h, int w);
 int ivr_frame_quality(ivr_ctx *ctx, const uint8_t *frames /*DEV*/, int n, int h, int w, int bgr, int canny_low, int canny_high,
                       int64_t *lap_sums /*DEV*/, int64_t *edge_count /*DEV*/, ivr_stream stream);

@@ -138,7 +138,7 @@ def test_quality_tiles_at_ragged_sizes_and_unaligned_frames(h, w, n):
 
 
 def test_quality_720p_batch_and_long_weak_chain():
-    """the hysteresis is a work list now; a 720p frame with one long weak chain hanging off a single strong spot must come
+    """the hysteresis follows chains (reconstruction sweeps over bit planes) instead of sweeping the frame a fixed number of times; a 720p frame with one long weak chain hanging off a single strong spot must come
     out with the oracle's exact edge count (the chain is as long as the frame is wide, several times)."""
     from ivr_amd.quality import frame_quality_scores
     h, w = 720, 1280

@@ -86,3 +86,50 @@ def test_gating_pipeline_matches_reference_logic(tmp_path):
     assert GQ.is_frame_acceptable_fixed(scores[8], cfg) == (False, "blur")
     assert GQ.is_frame_acceptable_fixed(scores[6], cfg) == (True, "acceptable")
     assert GQ.determine_adaptive_thresholds([], cfg) == (None, None)
+
+
+def _ridge_frame(h, w, rows, strong_at):
+    """Weak one-pixel-high horizontal ridges over the whole width (a run of candidates hundreds of 64-pixel words long) with one
+    strong spot each: the hysteresis has to carry the seed along the run across words, lanes and - past 4,096 pixels - across the
+    per-lane word chunks, in the direction the spot's position asks for."""
+    img = np.full((h, w), 100, np.uint8)
+    for r, sx in zip(rows, strong_at):
+        img[r, :] = 106
+        img[r, sx:sx + 3] = 255
+    return np.repeat(img[..., None], 3, axis=2)
+
+
+@pytest.mark.parametrize("h,w", [(9, 700), (12, 4200), (10, 9000), (7, 16384)])
+def test_long_runs_cross_words_and_chunks(h, w):
+    """One wave holds a whole row of the candidate plane, 1, 2 or 4 words per lane: seeds at the far left, the far right and the
+    middle of runs as wide as the frame, plus noise frames of the same shape."""
+    frames = np.stack([_ridge_frame(h, w, [2, 6], [0, w - 3]), _ridge_frame(h, w, [3, 5], [w // 2, 64 * (w // 128) - 1]),
+                       synth_frames(h + w, 1, h, w)[0]])
+    got = _check(frames, low=20, high=300)
+    assert got[0]["edge_density"] * h * w / 100 >= 2 * (w - 8)          # both ridges were followed to their ends
+
+
+def test_frames_wider_than_the_row_limit_are_refused():
+    import torch
+    from ivr_amd.quality import frame_quality_scores
+    with pytest.raises(Exception, match="wider"):
+        frame_quality_scores(torch.zeros((1, 2, 16385, 3), dtype=torch.uint8, device="cuda"))
+
+
+def test_vertical_serpentine_crosses_every_band_many_times():
+    """A three-pixel weak line that runs the frame's height up and down twenty times, tied to a single strong spot: every leg crosses
+    all the bands the sweep kernel cuts the frame into, and each reversal costs it another round."""
+    h, w, lw = 400, 330, 3
+    img = np.full((h, w), 100, np.uint8)
+    cols = list(range(12, w - 12 - lw, 15))
+    for i, x in enumerate(cols):
+        img[12:h - 12, x:x + lw] = 112
+        if i + 1 < len(cols):
+            if i % 2 == 0:
+                img[h - 12 - lw:h - 12, x:cols[i + 1] + lw] = 112
+            else:
+                img[12:12 + lw, x:cols[i + 1] + lw] = 112
+    img[12:16, 10:15] = 255
+    f = np.repeat(img[..., None], 3, axis=2)[None]
+    got = _check(f, low=20, high=300)
+    assert got[0]["edge_density"] * h * w / 100 > 1.5 * len(cols) * (h - 24)         # both flanks of every leg were reached

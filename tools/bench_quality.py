@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Frame-quality chain (ivr_frame_quality: gray + Laplacian sums + Sobel + NMS in one tiled kernel, work-list hysteresis) on
-batches of decoded frames resident in HBM: ms per batch and algorithmic GB/s (3 B read + 1 B mark written per pixel) against
+"""Frame-quality chain (ivr_frame_quality: gray + Laplacian sums + Sobel + NMS in one tiled kernel, hysteresis as reconstruction sweeps
+over bit planes) on batches of decoded frames resident in HBM: ms per batch and algorithmic GB/s (3 B read + 2 bits written per pixel) against
 the 8 TB/s HBM peak.
 
     python tools/bench_quality.py [frames=64]
@@ -50,6 +50,6 @@ for h, w, kind in ((1080, 1920, "smooth"), (1080, 1920, "noise"), (720, 1280, "s
     pr = {k: round(v["ms"] / 5, 3) for k, v in _ffi.profile_read().items()}
     npix = n * h * w
     tile_ms = pr.get("quality_tile", ms)
-    print(f"{n} x {h}x{w} {kind:6s}: {ms:7.3f} ms per batch ({npix * 4 / ms / 1e6:7.1f} GB/s algorithmic over the whole chain); tile kernel "
-          f"{tile_ms:.3f} ms = {npix * 4 / tile_ms / 1e6:7.1f} GB/s = {npix * 4 / tile_ms / 1e6 / 8000:.3f} of 8 TB/s; edges "
+    print(f"{n} x {h}x{w} {kind:6s}: {ms:7.3f} ms per batch ({npix * 3.25 / ms / 1e6:7.1f} GB/s algorithmic over the whole chain); tile kernel "
+          f"{tile_ms:.3f} ms = {npix * 3.25 / tile_ms / 1e6:7.1f} GB/s = {npix * 3.25 / tile_ms / 1e6 / 8000:.3f} of 8 TB/s; edges "
           f"{float(cnt.float().mean()) / (h * w) * 100:.1f} % of the pixels", pr)
