@@ -248,11 +248,12 @@ __device__ __forceinline__ bool sweep_band(const unsigned long long *__restrict_
     unsigned long long prev[KW], cb[PF][KW], sb[PF][KW], cn[PF][KW], sn[PF][KW];
     {
         // the neighbour band's boundary row: another wave of this workgroup may be writing it (bits only ever get set, words are
-        // written whole: a stale word costs a round, never a wrong bit)
+        // written whole: a stale word costs a round, never a wrong bit); read at agent scope, i.e. from L2, where the write-through stores
+        // of the other wave are once the barrier of the round has passed
         const int yn = down ? ya - 1 : yb;
 #pragma unroll
         for (int j = 0; j < KW; ++j)
-            prev[j] = (yn >= 0 && yn < h && valid[j]) ? __hip_atomic_load(S + (int64_t)yn * w64 + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+            prev[j] = (yn >= 0 && yn < h && valid[j]) ? __hip_atomic_load(S + (int64_t)yn * w64 + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     }
     auto fetch = [&](int r0, unsigned long long (&cc)[PF][KW], unsigned long long (&ss)[PF][KW]) {
 #pragma unroll

@@ -133,3 +133,19 @@ def test_vertical_serpentine_crosses_every_band_many_times():
     f = np.repeat(img[..., None], 3, axis=2)[None]
     got = _check(f, low=20, high=300)
     assert got[0]["edge_density"] * h * w / 100 > 1.5 * len(cols) * (h - 24)         # both flanks of every leg were reached
+
+
+def test_random_shapes_thresholds_and_channel_orders():
+    """Forty seeded draws of (h, w, low, high, bgr): widths around the 64-pixel word and tile edges, heights around the 32-row tile
+    and the 16-row band edges, thresholds from 'everything is an edge' to 'nothing is'."""
+    rng = np.random.default_rng(2024)
+    widths = [1, 2, 3, 31, 62, 63, 64, 65, 66, 67, 126, 127, 128, 129, 130, 191, 193, 255, 257]
+    heights = [1, 2, 15, 16, 17, 30, 31, 32, 33, 34, 47, 48, 49, 63, 64, 65, 66, 95, 97]
+    for i in range(40):
+        h, w = int(rng.choice(heights)), int(rng.choice(widths))
+        low = int(rng.choice([0, 5, 20, 60, 200, 2040]))
+        high = low + int(rng.choice([0, 1, 40, 300]))
+        smooth = smooth_frames(1000 + i, 1, h, w)
+        noise = synth_frames(2000 + i, 1, h, w)
+        mix = ((smooth.astype(np.int32) * 3 + noise.astype(np.int32)) // 4).astype(np.uint8)
+        _check(np.concatenate([smooth, noise, mix]), bgr=bool(i & 1), low=low, high=high)
