@@ -170,7 +170,11 @@ def side_configs(dev, weights_b32):
         st["graph_replay_ms" if use_graph else "plain_launch_ms"] = (time.perf_counter() - t0) / 100 * 1e3
     st["real_time_margin"] = (1000.0 / 30.0) / st["graph_replay_ms"]
     out["configs3_streaming_step"] = st
-    del index, tower, sess
+    del tower, sess
+    # the reference's interactive path, one text query per call (system.py:733 -> core.py:1504 encode_text -> unified_index.py:480
+    # search_vectors, k = 50): wall clock from Python, host buffers in and out, against this 5M-row index
+    out["interactive_text_query"] = interactive_query(dev, index)
+    del index
     torch.cuda.empty_cache()
     cfg = C.CLIP_VIT_L14
     wl = make_weights(cfg, 12)
@@ -192,6 +196,36 @@ def side_configs(dev, weights_b32):
                    "(1 - cos <= 1e-3, text-query scores ~2e-3); fp8_all = all four sites in e4m3 (1 - cos ~ 4e-3): tests/test_fp8_gpu.py, "
                    "profiles/r02_fp8_error_budget.json")
     out["configs4_tower_vit_l14"] = l14
+    return out
+
+
+def interactive_query(dev, index, calls=100):
+    """One text query -> top-50, the way system.search() issues it: CLIPFeatureExtractor.encode_text (ViT-B/32 text tower, random-init,
+    byte-level stand-in tokenizer: 77 token ids as in the reference) and FlatIPIndex.search with a host query vector, median wall-clock
+    milliseconds per call.  The reference logged 38 - 273 ms for the encoder alone on its CUDA box (logs/performance.log:2-7)."""
+    from ivr_amd.compat import CLIPFeatureExtractor
+
+    def med(fn):
+        for _ in range(5):
+            fn()
+        ts = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts))
+    text = "a person riding a bicycle at night"
+    out = {"rows": int(index.ntotal), "d": 512, "k": 50, "calls": calls}
+    for tc in ("f32", "bf16"):
+        ex = CLIPFeatureExtractor("openai/clip-vit-base-patch32", allow_random_init=True, max_batch=8, text_compute=tc)
+        qv = ex.encode_text(text)
+        out[f"encode_text_{tc}_ms"] = med(lambda: ex.encode_text(text))
+        if tc == "f32":
+            out["search_ms"] = med(lambda: index.search(qv, 50))
+        out[f"text_to_top50_{tc}_ms"] = med(lambda: index.search(ex.encode_text(text), 50))
+        del ex
+    out["note"] = ("compat.CLIPFeatureExtractor runs text queries through the float32 text tower by default (text-vs-image scores within 1e-3 of "
+                   "the float32 reference); reference log: 38 - 273 ms per text query for the encoder alone (logs/performance.log:2-7)")
     return out
 
 

@@ -36,7 +36,6 @@ template <typename T>
 struct El;
 template <>
 struct El<unsigned short> {
-    [[maybe_unused]] static constexpr int per16 = 8;   // elements per 16 bytes (attention_kernel chunking)
     static __device__ __forceinline__ void unpack(const uint4 &u, float (&f)[8]) {
         f[0] = __uint_as_float(u.x << 16);
         f[1] = __uint_as_float(u.x & 0xffff0000u);
@@ -73,7 +72,6 @@ struct El<unsigned char> {       // e4m3 activations of the fp8 mode
 };
 template <>
 struct El<float> {
-    static constexpr int per16 = 4;
     static __device__ __forceinline__ void store4(float *p, const float (&v)[4]) {
         *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -1013,38 +1011,45 @@ __device__ __forceinline__ void load_row64<float>(const float *p, float (&f)[64]
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(512) void attention_kernel(const T *__restrict__ qkv, T *__restrict__ att, int Tn, int D, int causal) {
+// float32 verification / query mode.  KS lanes share a query row: lane part p takes the keys j = p (mod KS) with its own online-softmax
+// state (m, l, o[64]); the KS states of a row sit in adjacent lanes and are merged by log2(KS) xor-shuffle rounds.  One text query is 77
+// rows x 8 heads: with one lane per row (KS = 1) a head was a 77-key serial chain on two waves (40 us, a third of the float32 text
+// tower's latency); KS = 4 cuts the chain to 20 keys.  K / V rows are padded to 68 floats in LDS: the KS rows a wave reads at once fall
+// into distinct banks.
+constexpr int AF_STRIDE = 68;
+template <int KS>
+__global__ __launch_bounds__(512) void attention_f32_kernel(const float *__restrict__ qkv, float *__restrict__ att, int Tn, int D, int causal) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *Ks = reinterpret_cast<T *>(smem);
-    T *Vs = Ks + (size_t)Tn * 64;
+    float *Ks = reinterpret_cast<float *>(smem);
+    float *Vs = Ks + (size_t)Tn * AF_STRIDE;
     const int h = blockIdx.x, img = blockIdx.y;
     const int64_t base = (int64_t)img * Tn * 3 * D + h * 64;
-    constexpr int C16 = 64 / El<T>::per16;   // 16-byte chunks per 64-element row
-    for (int i = threadIdx.x; i < Tn * C16; i += blockDim.x) {
-        const int t = i / C16, c = i % C16;
-        const uint4 *kp = reinterpret_cast<const uint4 *>(qkv + base + (int64_t)t * 3 * D + D) + c;
-        const uint4 *vp = reinterpret_cast<const uint4 *>(qkv + base + (int64_t)t * 3 * D + 2 * D) + c;
-        reinterpret_cast<uint4 *>(Ks)[i] = *kp;
-        reinterpret_cast<uint4 *>(Vs)[i] = *vp;
+    for (int i = threadIdx.x; i < Tn * 16; i += blockDim.x) {
+        const int t = i >> 4, c = i & 15;
+        const float4 *kp = reinterpret_cast<const float4 *>(qkv + base + (int64_t)t * 3 * D + D) + c;
+        const float4 *vp = reinterpret_cast<const float4 *>(qkv + base + (int64_t)t * 3 * D + 2 * D) + c;
+        reinterpret_cast<float4 *>(Ks + t * AF_STRIDE)[c] = *kp;
+        reinterpret_cast<float4 *>(Vs + t * AF_STRIDE)[c] = *vp;
     }
     __syncthreads();
-    const int t = threadIdx.x;
+    const int t = threadIdx.x / KS, part = threadIdx.x % KS;
     const bool active = t < Tn;
     float q[64], o[64];
-    if (active) load_row64<T>(qkv + base + (int64_t)t * 3 * D, q);
+    if (active) load_row64<float>(qkv + base + (int64_t)t * 3 * D, q);
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
         o[i] = 0.f;
         if (!active) q[i] = 0.f;
     }
     float m = -INFINITY, l = 0.f;
-    // wave-uniform key bound: all keys, or (last query of this wave) + 1 under the causal mask
+    // wave-uniform key bound: all keys, or (last query row of this wave) + 1 under the causal mask
     int jmax = Tn;
-    if (causal) jmax = min(Tn, (int)((threadIdx.x | 63) + 1));
-    for (int j = 0; j < jmax; ++j) {
+    if (causal) jmax = min(Tn, (int)((threadIdx.x | 63) / KS + 1));
+    for (int j0 = 0; j0 < jmax; j0 += KS) {
+        const int j = j0 + part;
+        const bool jin = j < jmax;
         float kv[64];
-        load_row64<T>(Ks + (size_t)j * 64, kv);
+        load_row64<float>(Ks + (size_t)min(j, Tn - 1) * AF_STRIDE, kv);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int i = 0; i < 64; i += 4) {
@@ -1054,7 +1059,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const T *__restrict__ qk
             s3 = fmaf(q[i + 3], kv[i + 3], s3);
         }
         float s = (s0 + s1) + (s2 + s3);
-        if (causal && j > t) s = -INFINITY;
+        if (!jin || (causal && j > t)) s = -INFINITY;
         if (__any(s > m)) {
             const float mn = fmaxf(m, s);
             const float alpha = (m == -INFINITY) ? 0.f : __expf(m - mn);
@@ -1065,18 +1070,26 @@ __global__ __launch_bounds__(512) void attention_kernel(const T *__restrict__ qk
         }
         const float p = (s == -INFINITY) ? 0.f : __expf(s - m);
         l += p;
-        load_row64<T>(Vs + (size_t)j * 64, kv);
+        load_row64<float>(Vs + (size_t)min(j, Tn - 1) * AF_STRIDE, kv);
 #pragma unroll
         for (int i = 0; i < 64; ++i) o[i] = fmaf(p, kv[i], o[i]);
     }
-    if (active) {
-        const float inv = 1.0f / l;
-        T *op = att + ((int64_t)img * Tn + t) * D + h * 64;
+    // merge the KS partial states of a row (adjacent lanes)
 #pragma unroll
-        for (int i = 0; i < 64; i += 4) {
-            const float v[4] = {o[i] * inv, o[i + 1] * inv, o[i + 2] * inv, o[i + 3] * inv};
-            El<T>::store4(op + i, v);
-        }
+    for (int off = 1; off < KS; off <<= 1) {
+        const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
+        const float mn = fmaxf(m, m2);
+        const float a = (m == -INFINITY) ? 0.f : __expf(m - mn), b2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+        l = l * a + l2 * b2;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) o[i] = o[i] * a + __shfl_xor(o[i], off, 64) * b2;
+        m = mn;
+    }
+    if (active && part == 0) {
+        const float inv = 1.0f / l;
+        float *op = att + ((int64_t)img * Tn + t) * D + h * 64;
+#pragma unroll
+        for (int i = 0; i < 64; i += 4) *reinterpret_cast<float4 *>(op + i) = make_float4(o[i] * inv, o[i + 1] * inv, o[i + 2] * inv, o[i + 3] * inv);
     }
 }
 
@@ -2565,6 +2578,103 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmArgs g) {
 #undef GP_LGKM
 }
 
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMM: M <= 128 rows - one text query (77 rows) or one image of a 7 x 7 grid (50 rows).
+// The interactive path of the reference (system.py:733 -> core.py:1504) encodes ONE query per call: with 128 x 128 tiles such a
+// product has N / 128 workgroups (4 for N = 512) that each walk the whole K alone: 86 us per residual product of the float32 text
+// tower.  Here a workgroup owns 16 output columns and a wave one 16 x 16 output tile of them (up to eight waves): N / 16 workgroups
+// on as many CUs.  The workgroup's weight panel (16 rows x K, the only operand that comes from HBM) is fetched by LDS-DMA, ALL of it
+// in flight at once (no registers involved: one memory latency per panel of up to 128 KiB instead of one per few K steps); the
+// activation rows come from L2 straight into the MFMA fragment registers, five K steps ahead.  The loop body is branch-free (the
+// step index of a load is clamped, the last steps are peeled) so that the compiler's vmcnt counting keeps those loads in flight.
+// The accumulation order over K is the tiled kernels' (one fp32 accumulator per output, K steps in ascending order, the same MFMA
+// per chunk), so a row's result does not depend on the batch it was encoded in.
+// ---------------------------------------------------------------------------------------------
+constexpr int SKINNY_MAX_STEPS = 64;                 // K steps (of ROWB bytes) per LDS panel: 64 x 2 KiB = 128 KiB
+
+template <typename T, int EPI, int ACT>
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ES = (int)sizeof(T), DEPTH = 6;
+    const int lane = threadIdx.x & 63, r = lane & 15, kg = lane >> 4;
+    const int mt = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), nw = (int)blockDim.x >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int steps = g.K * ES / ROWB;
+    const char *xp = reinterpret_cast<const char *>(g.A) + (int64_t)min(mt * 16 + r, g.M - 1) * g.lda * ES + kg * 16;
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * ES), 0x00020000);
+    // DMA piece = 8 rows x 128 B: lane l lands at 16 l = row (l >> 3), chunk position l & 7, and fetches logical chunk (l & 7) ^ row
+    // (the tiled kernels' source-side swizzle); fragment reads apply the same involution
+    const unsigned voff0 = (unsigned)((n0 + (lane >> 3)) * g.ldw) * ES + (((lane & 7) ^ (lane >> 3)) << 4);
+    const unsigned voff1 = voff0 + (unsigned)(8 * g.ldw) * ES;
+    unsigned fo[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fo[kk] = r * ROWB + ((((kk << 2) + kg) ^ (r & 7)) << 4);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < steps; c0 += SKINNY_MAX_STEPS) {
+        const int cs = min(SKINNY_MAX_STEPS, steps - c0), last = c0 + cs - 1;
+        u32x4 xf[DEPTH][2];
+        auto load = [&](int st, int b) {
+            const int64_t off = (int64_t)min(st, last) * ROWB;
+            xf[b][0] = *reinterpret_cast<const u32x4 *>(xp + off);
+            xf[b][1] = *reinterpret_cast<const u32x4 *>(xp + off + 64);
+        };
+        auto compute = [&](int st, int b) {
+            const unsigned char *p = smem + (st - c0) * 2048;
+            const u32x4 w0 = *reinterpret_cast<const u32x4 *>(p + fo[0]), w1 = *reinterpret_cast<const u32x4 *>(p + fo[1]);
+            mma_chunk<T>(w0, xf[b][0], acc);
+            mma_chunk<T>(w1, xf[b][1], acc);
+        };
+#pragma unroll
+        for (int b = 0; b < DEPTH - 1; ++b) load(c0 + b, b);
+        if (c0) __syncthreads();                                  // every wave has read the previous panel
+        for (int q = mt; q < cs; q += nw) {       // the two pieces of K step c0 + q; per-lane offsets stay in two fixed registers, the step is scalar
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(smem + q * 2048), 16, voff0,
+                                                     (unsigned)(c0 + q) * ROWB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(smem + q * 2048 + 1024), 16, voff1,
+                                                     (unsigned)(c0 + q) * ROWB, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int st = c0;
+        for (; st + DEPTH <= c0 + cs; st += DEPTH) {
+#pragma unroll
+            for (int b = 0; b < DEPTH; ++b) {
+                load(st + b + DEPTH - 1, (b + DEPTH - 1) % DEPTH);       // buffer of step st + b - 1, consumed just before
+                compute(st + b, b);
+            }
+        }
+        const int rem = c0 + cs - st;                                     // the last steps (fewer than DEPTH): buffer b holds step st + b
+#pragma unroll
+        for (int b = 0; b < DEPTH - 1; ++b)
+            if (b < rem) compute(st + b, b);
+    }
+    // epilogue: lane holds C[m][n .. n+3], m = mt * 16 + (lane & 15), n = n0 + 4 * (lane >> 4)
+    const int ncol = n0 + 4 * kg, m = mt * 16 + r;
+    if (m >= g.M) return;
+    const float4 bv = g.bias ? *reinterpret_cast<const float4 *>(g.bias + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float v[4] = {acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w};
+    if (EPI == EPI_RESID) {
+        if (g.skip_mod && m % g.skip_mod == 0) return;
+        float4 *p = reinterpret_cast<float4 *>(g.resid + (int64_t)m * g.ldr + ncol);
+        const float4 rv = *p;
+        *p = make_float4(rv.x + v[0], rv.y + v[1], rv.z + v[2], rv.w + v[3]);      // residual + (accumulator + bias), as in the tiled kernels
+    } else if (EPI == EPI_PATCH) {
+        const int img = m / g.G2, pch = m % g.G2;
+        const float4 pv = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol);
+        *reinterpret_cast<float4 *>(g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr + ncol) =
+            make_float4(pv.x + v[0], pv.y + v[1], pv.z + v[2], pv.w + v[3]);
+    } else {
+        if (ACT >= 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
+        }
+        if (EPI == EPI_STORE)
+            El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)m * g.ldo + ncol, v);
+        else
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)m * g.ldo + ncol) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 static int device_cu_count() {
     static std::mutex mu;
     static std::map<int, int> cus;
@@ -2583,6 +2693,20 @@ template <typename T, int EPI, int ACT>
 int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
     int mode = gemm_mode();
+    {
+        // at most 128 rows (one query, one image of a 7 x 7 grid): one wave per 16 x 16 output tile, see gemm_skinny_kernel
+        const auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+        const int64_t es = sizeof(T);
+        if (g.M <= 128 && mode < 0 && env_int("IVR_GEMM_SKINNY", 1) && g.N % 16 == 0 && g.lda * es % 16 == 0 && g.ldw * es % 16 == 0 && al16(g.A) &&
+            al16(g.W) && al16(g.bias) && (EPI == EPI_STORE || EPI == EPI_F32 ? al16(g.out) && g.ldo % 4 == 0 : al16(g.resid) && g.ldr % 4 == 0) &&
+            (EPI != EPI_PATCH || (al16(g.pos) && g.N % 4 == 0))) {
+            const int lds = std::min(SKINNY_MAX_STEPS, (int)(g.K * es / ROWB)) * 2048;
+            if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(gemm_skinny_kernel<T, EPI, ACT>), SKINNY_MAX_STEPS * 2048)) return rc;
+            hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, ACT>), dim3(g.N / 16), dim3(64 * ((g.M + 15) / 16)), lds, s, g);
+            IVR_LAUNCH_CHECK();
+            return IVR_OK;
+        }
+    }
     // default (-1): the 256 x 256 kernel once it fills the chip, the 128 x 128 kernel for small problems
     // (measured on ViT-B/32: at 150 tiles the large kernel already wins by 8 %, at 117 the small one by 7 %)
     if (mode < 0) mode = ((g.M + LBM - 1) / LBM) * ((g.N + LBN - 1) / LBN) >= 128 ? 4 : 0;
@@ -2924,15 +3048,21 @@ int ivr_launch_attention(bool f32, const void *qkv, void *att, int n, int T, int
         IVR_LAUNCH_CHECK();
         return IVR_OK;
     }
-    // float32 verification mode: one query per lane, K/V in LDS, VALU dot products
-    const int threads = (int)ivr_round_up(T, 64);
-    IVR_REQUIRE(threads <= 512, "attention: T=%d too long for the float32 kernel", T);
-    const size_t lds = (size_t)2 * T * 64 * 4;
+    // float32 verification / query mode: KS lanes per query row, K/V in LDS, VALU dot products
+    IVR_REQUIRE(T <= 512, "attention: T=%d too long for the float32 kernel", T);
+    const size_t lds = (size_t)2 * T * AF_STRIDE * 4;
     IVR_REQUIRE(lds <= 160 * 1024, "attention: T=%d needs %zu bytes of LDS", T, lds);
-    if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(attention_kernel<float>), (int)lds)) return rc;
-    hipLaunchKernelGGL(attention_kernel<float>, dim3(heads, n), dim3(threads), lds, s, (const float *)qkv, (float *)att, T, D, causal);
-    IVR_LAUNCH_CHECK();
-    return IVR_OK;
+    const int ks = T * 8 <= 512 ? 8 : (T * 4 <= 512 ? 4 : (T * 2 <= 512 ? 2 : 1));          // 192 registers of state per lane: at most 512 lanes
+    const int threads = (int)ivr_round_up((int64_t)T * ks, 64);
+    auto go = [&](auto ks_c) -> int {
+        constexpr int KS = decltype(ks_c)::value;
+        if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(attention_f32_kernel<KS>), (int)lds)) return rc;
+        hipLaunchKernelGGL(attention_f32_kernel<KS>, dim3(heads, n), dim3(threads), lds, s, (const float *)qkv, (float *)att, T, D, causal);
+        IVR_LAUNCH_CHECK();
+        return IVR_OK;
+    };
+    return ks == 8 ? go(std::integral_constant<int, 8>{}) : ks == 4 ? go(std::integral_constant<int, 4>{})
+           : ks == 2 ? go(std::integral_constant<int, 2>{}) : go(std::integral_constant<int, 1>{});
 }
 
 int ivr_launch_vision_cls(float *resid, const float *cls, const float *pos, int n, int T, int D, hipStream_t s) {

@@ -271,9 +271,10 @@ class CLIPFeatureExtractor:
         self.text_model = None
         if with_text:
             tw = self._resolve(txt_cfg, text_weights, seed + 1)
-            # Queries are a handful of rows per search (core.py:1504 encodes one string): the float32 tower costs microseconds more
-            # and keeps text-vs-image scores within the 1e-3 bound - the bf16 text tower alone moves them by up to 1.1e-3
-            # (DESIGN.md section 4, fp8 table).  text_compute="bf16" restores the fast mode for bulk text encoding.
+            # Queries are a handful of rows per search (core.py:1504 encodes one string): the float32 tower costs 0.4 ms more per
+            # query (1.0 vs 0.6 ms for ViT-B/32, tools/bench_query_latency.py) and keeps text-vs-image scores within the 1e-3 bound -
+            # the bf16 text tower alone moves them by up to 1.1e-3.  text_compute="bf16" restores
+            # the fast mode for bulk text encoding.
             self.text_model = Tower(txt_cfg, tw, max_batch=64, compute=text_compute)
         self.model = self.vision_model    # truthy: health check at system.py:263
         if tokenizer is None and isinstance(model_path, str) and os.path.isfile(os.path.join(model_path, "vocab.json")):

@@ -150,3 +150,30 @@ def test_persistent_kernel_is_bit_identical_to_the_tile_per_workgroup_kernel(M, 
     linear(xi, wi, None, epilogue=EPI_RESID, resid=ri)
     pick = torch.tensor([0, 1, 257, M // 3, M - 1], device="cuda")
     assert torch.equal(ri[pick], xi[pick].float() @ wi.float().T)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (16, 512, 512), (50, 768, 3072), (77, 2048, 512), (77, 512, 2048), (113, 2304, 768), (128, 3072, 1024),
+                                   (49, 768, 3072)])
+def test_skinny_kernel_is_bit_identical_to_the_tiled_kernels(dtype, M, N, K, monkeypatch):
+    """Up to 128 rows (one text query, one image) the launcher takes gemm_skinny_kernel: one wave per 16 output columns, operands from L2
+    straight into the MFMA fragments.  Same accumulation order over K as the tiled kernels -> the same bits for every epilogue, so a
+    row's embedding does not depend on the size of the batch it was encoded in."""
+    from ivr_amd.linear import EPI_F32, EPI_RESID, linear
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+    x = (torch.randn((M, K), generator=g, device="cuda") * 0.7).to(dtype)
+    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(dtype)
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    r0 = torch.randn((M, N), generator=g, device="cuda")
+
+    def run():
+        return ([linear(x, w, b, act=a) for a in (-1, 0, 1)] + [linear(x, w, None), linear(x, w, b, epilogue=EPI_RESID, resid=r0.clone()),
+                                                                linear(x, w, None, epilogue=EPI_F32)])
+    monkeypatch.setenv("IVR_GEMM_SKINNY", "1")
+    skinny = run()
+    monkeypatch.setenv("IVR_GEMM_SKINNY", "0")
+    tiled = run()
+    for a, t in zip(skinny, tiled):
+        assert torch.equal(a, t)
+    ref = _ref(x, w, b, -1)
+    assert (skinny[0].float().cpu() - ref).abs().max() <= (2e-5 if dtype == torch.float32 else 1.2e-2) * max(1.0, ref.abs().max())
