@@ -2582,8 +2582,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmArgs g) {
 // Skinny GEMM: M <= 128 rows - one text query (77 rows) or one image of a 7 x 7 grid (50 rows).
 // The interactive path of the reference (system.py:733 -> core.py:1504) encodes ONE query per call: with 128 x 128 tiles such a
 // product has N / 128 workgroups (4 for N = 512) that each walk the whole K alone: 86 us per residual product of the float32 text
-// tower.  Here a workgroup owns 16 output columns and a wave one 16 x 16 output tile of them (up to eight waves): N / 16 workgroups
-// on as many CUs.  The workgroup's weight panel (16 rows x K, the only operand that comes from HBM) is fetched by LDS-DMA, ALL of it
+// tower.  Here a workgroup owns 16 output columns and a wave one to three 16 x 16 output tiles of them (up to eight waves): N / 16
+// workgroups on as many CUs.  The workgroup's weight panel (16 rows x K, the only operand that comes from HBM) is fetched by LDS-DMA, ALL of it
 // in flight at once (no registers involved: one memory latency per panel of up to 128 KiB instead of one per few K steps); the
 // activation rows come from L2 straight into the MFMA fragment registers, five K steps ahead.  The loop body is branch-free (the
 // step index of a load is clamped, the last steps are peeled) so that the compiler's vmcnt counting keeps those loads in flight.
@@ -2591,16 +2591,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmArgs g) {
 // per chunk), so a row's result does not depend on the batch it was encoded in.
 // ---------------------------------------------------------------------------------------------
 constexpr int SKINNY_MAX_STEPS = 64;                 // K steps (of ROWB bytes) per LDS panel: 64 x 2 KiB = 128 KiB
+// Row tiles per wave the launcher uses.  The kernel takes MTL = 1 ... 3 (up to 384 rows), but past 128 rows every one of the N / 16
+// workgroups re-reads the whole activation panel from L2 and that traffic takes over: measured with MTL = 2 / 3, one DINO frame (197 rows)
+// gained 5 %, one ViT-L/14 image (257 rows) lost 9 % against the 128 x 128 tiled kernel.
+constexpr int kSkinnyMaxMtl = 1;
 
-template <typename T, int EPI, int ACT>
+template <typename T, int EPI, int ACT, int MTL>
 __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int ES = (int)sizeof(T), DEPTH = 6;
+    constexpr int ES = (int)sizeof(T), DEPTH = MTL == 1 ? 6 : 4;
     const int lane = threadIdx.x & 63, r = lane & 15, kg = lane >> 4;
-    const int mt = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), nw = (int)blockDim.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), nw = (int)blockDim.x >> 6;
     const int n0 = blockIdx.x * 16;
     const int steps = g.K * ES / ROWB;
-    const char *xp = reinterpret_cast<const char *>(g.A) + (int64_t)min(mt * 16 + r, g.M - 1) * g.lda * ES + kg * 16;
+    const char *xp[MTL];                              // wave wv owns row tiles wv * MTL .. wv * MTL + MTL - 1 (rows past M read row M - 1)
+#pragma unroll
+    for (int i = 0; i < MTL; ++i)
+        xp[i] = reinterpret_cast<const char *>(g.A) + (int64_t)min((wv * MTL + i) * 16 + r, g.M - 1) * g.lda * ES + kg * 16;
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.W), 0, (int)((int64_t)g.N * g.ldw * ES), 0x00020000);
     // DMA piece = 8 rows x 128 B: lane l lands at 16 l = row (l >> 3), chunk position l & 7, and fetches logical chunk (l & 7) ^ row
     // (the tiled kernels' source-side swizzle); fragment reads apply the same involution
@@ -2609,25 +2616,32 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs g) {
     unsigned fo[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) fo[kk] = r * ROWB + ((((kk << 2) + kg) ^ (r & 7)) << 4);
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MTL];
+#pragma unroll
+    for (int i = 0; i < MTL; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < steps; c0 += SKINNY_MAX_STEPS) {
         const int cs = min(SKINNY_MAX_STEPS, steps - c0), last = c0 + cs - 1;
-        u32x4 xf[DEPTH][2];
+        u32x4 xf[DEPTH][MTL][2];
         auto load = [&](int st, int b) {
             const int64_t off = (int64_t)min(st, last) * ROWB;
-            xf[b][0] = *reinterpret_cast<const u32x4 *>(xp + off);
-            xf[b][1] = *reinterpret_cast<const u32x4 *>(xp + off + 64);
+#pragma unroll
+            for (int i = 0; i < MTL; ++i) {
+                xf[b][i][0] = *reinterpret_cast<const u32x4 *>(xp[i] + off);
+                xf[b][i][1] = *reinterpret_cast<const u32x4 *>(xp[i] + off + 64);
+            }
         };
         auto compute = [&](int st, int b) {
             const unsigned char *p = smem + (st - c0) * 2048;
             const u32x4 w0 = *reinterpret_cast<const u32x4 *>(p + fo[0]), w1 = *reinterpret_cast<const u32x4 *>(p + fo[1]);
-            mma_chunk<T>(w0, xf[b][0], acc);
-            mma_chunk<T>(w1, xf[b][1], acc);
+#pragma unroll
+            for (int i = 0; i < MTL; ++i) mma_chunk<T>(w0, xf[b][i][0], acc[i]);
+#pragma unroll
+            for (int i = 0; i < MTL; ++i) mma_chunk<T>(w1, xf[b][i][1], acc[i]);
         };
 #pragma unroll
         for (int b = 0; b < DEPTH - 1; ++b) load(c0 + b, b);
         if (c0) __syncthreads();                                  // every wave has read the previous panel
-        for (int q = mt; q < cs; q += nw) {       // the two pieces of K step c0 + q; per-lane offsets stay in two fixed registers, the step is scalar
+        for (int q = wv; q < cs; q += nw) {       // the two pieces of K step c0 + q; per-lane offsets stay in two fixed registers, the step is scalar
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(smem + q * 2048), 16, voff0,
                                                      (unsigned)(c0 + q) * ROWB, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void *)(smem + q * 2048 + 1024), 16, voff1,
@@ -2648,30 +2662,34 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs g) {
         for (int b = 0; b < DEPTH - 1; ++b)
             if (b < rem) compute(st + b, b);
     }
-    // epilogue: lane holds C[m][n .. n+3], m = mt * 16 + (lane & 15), n = n0 + 4 * (lane >> 4)
-    const int ncol = n0 + 4 * kg, m = mt * 16 + r;
-    if (m >= g.M) return;
+    // epilogue: lane holds C[m][n .. n+3], m = tile * 16 + (lane & 15), n = n0 + 4 * (lane >> 4)
+    const int ncol = n0 + 4 * kg;
     const float4 bv = g.bias ? *reinterpret_cast<const float4 *>(g.bias + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float v[4] = {acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w};
-    if (EPI == EPI_RESID) {
-        if (g.skip_mod && m % g.skip_mod == 0) return;
-        float4 *p = reinterpret_cast<float4 *>(g.resid + (int64_t)m * g.ldr + ncol);
-        const float4 rv = *p;
-        *p = make_float4(rv.x + v[0], rv.y + v[1], rv.z + v[2], rv.w + v[3]);      // residual + (accumulator + bias), as in the tiled kernels
-    } else if (EPI == EPI_PATCH) {
-        const int img = m / g.G2, pch = m % g.G2;
-        const float4 pv = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol);
-        *reinterpret_cast<float4 *>(g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr + ncol) =
-            make_float4(pv.x + v[0], pv.y + v[1], pv.z + v[2], pv.w + v[3]);
-    } else {
-        if (ACT >= 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = act_fn<sizeof(T) == 2>(v[i], ACT);
+    for (int i = 0; i < MTL; ++i) {
+        const int m = (wv * MTL + i) * 16 + r;
+        if (m >= g.M) continue;
+        float v[4] = {acc[i][0] + bv.x, acc[i][1] + bv.y, acc[i][2] + bv.z, acc[i][3] + bv.w};
+        if (EPI == EPI_RESID) {
+            if (g.skip_mod && m % g.skip_mod == 0) continue;
+            float4 *p = reinterpret_cast<float4 *>(g.resid + (int64_t)m * g.ldr + ncol);
+            const float4 rv = *p;
+            *p = make_float4(rv.x + v[0], rv.y + v[1], rv.z + v[2], rv.w + v[3]);      // residual + (accumulator + bias), as in the tiled kernels
+        } else if (EPI == EPI_PATCH) {
+            const int img = m / g.G2, pch = m % g.G2;
+            const float4 pv = *reinterpret_cast<const float4 *>(g.pos + (int64_t)(1 + pch) * g.N + ncol);
+            *reinterpret_cast<float4 *>(g.resid + ((int64_t)img * g.T + 1 + pch) * g.ldr + ncol) =
+                make_float4(pv.x + v[0], pv.y + v[1], pv.z + v[2], pv.w + v[3]);
+        } else {
+            if (ACT >= 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_fn<sizeof(T) == 2>(v[j], ACT);
+            }
+            if (EPI == EPI_STORE)
+                El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)m * g.ldo + ncol, v);
+            else
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)m * g.ldo + ncol) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        if (EPI == EPI_STORE)
-            El<T>::store4(reinterpret_cast<T *>(g.out) + (int64_t)m * g.ldo + ncol, v);
-        else
-            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(g.out) + (int64_t)m * g.ldo + ncol) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -2694,17 +2712,24 @@ int launch_gemm_t(const GemmArgs &g, hipStream_t s) {
     IvrProf prof(g.tag ? g.tag : "gemm", s, 2.0 * g.M * g.N * g.K);
     int mode = gemm_mode();
     {
-        // at most 128 rows (one query, one image of a 7 x 7 grid): one wave per 16 x 16 output tile, see gemm_skinny_kernel
+        // at most 128 rows (one text query, one ViT-B/32 image): see gemm_skinny_kernel
         const auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
         const int64_t es = sizeof(T);
-        if (g.M <= 128 && mode < 0 && env_int("IVR_GEMM_SKINNY", 1) && g.N % 16 == 0 && g.lda * es % 16 == 0 && g.ldw * es % 16 == 0 && al16(g.A) &&
+        if (g.M <= 128 * kSkinnyMaxMtl && mode < 0 && env_int("IVR_GEMM_SKINNY", 1) && g.N % 16 == 0 && g.lda * es % 16 == 0 && g.ldw * es % 16 == 0 && al16(g.A) &&
             al16(g.W) && al16(g.bias) && (EPI == EPI_STORE || EPI == EPI_F32 ? al16(g.out) && g.ldo % 4 == 0 : al16(g.resid) && g.ldr % 4 == 0) &&
             (EPI != EPI_PATCH || (al16(g.pos) && g.N % 4 == 0))) {
             const int lds = std::min(SKINNY_MAX_STEPS, (int)(g.K * es / ROWB)) * 2048;
-            if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(gemm_skinny_kernel<T, EPI, ACT>), SKINNY_MAX_STEPS * 2048)) return rc;
-            hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, ACT>), dim3(g.N / 16), dim3(64 * ((g.M + 15) / 16)), lds, s, g);
-            IVR_LAUNCH_CHECK();
-            return IVR_OK;
+            const int tiles = (g.M + 15) / 16, mtl = (tiles + 7) / 8, nw = (tiles + mtl - 1) / mtl;     // 1 .. 3 row tiles per wave, at most 8 waves
+            auto go = [&](auto mtl_c) -> int {
+                constexpr int MTL = decltype(mtl_c)::value;
+                if (int rc = ivr_func_max_lds(reinterpret_cast<const void *>(gemm_skinny_kernel<T, EPI, ACT, MTL>), SKINNY_MAX_STEPS * 2048)) return rc;
+                hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, ACT, MTL>), dim3(g.N / 16), dim3(64 * nw), lds, s, g);
+                IVR_LAUNCH_CHECK();
+                return IVR_OK;
+            };
+            static_assert(kSkinnyMaxMtl == 1, "add the MTL instantiations");
+            (void)mtl;
+            return go(std::integral_constant<int, 1>{});
         }
     }
     // default (-1): the 256 x 256 kernel once it fills the chip, the 128 x 128 kernel for small problems

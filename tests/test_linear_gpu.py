@@ -154,10 +154,10 @@ def test_persistent_kernel_is_bit_identical_to_the_tile_per_workgroup_kernel(M, 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(1, 64, 64), (16, 512, 512), (50, 768, 3072), (77, 2048, 512), (77, 512, 2048), (113, 2304, 768), (128, 3072, 1024),
-                                   (49, 768, 3072)])
+                                   (49, 768, 3072), (127, 384, 1536), (128, 1152, 384), (129, 512, 512)])
 def test_skinny_kernel_is_bit_identical_to_the_tiled_kernels(dtype, M, N, K, monkeypatch):
-    """Up to 128 rows (one text query, one image) the launcher takes gemm_skinny_kernel: one wave per 16 output columns, operands from L2
-    straight into the MFMA fragments.  Same accumulation order over K as the tiled kernels -> the same bits for every epilogue, so a
+    """Up to 128 rows (one text query, one ViT-B/32 image) the launcher takes gemm_skinny_kernel: a wave per 16 x 16 output tile, the
+    weight panel by LDS-DMA, activations from L2 straight into the MFMA fragments (129 rows: both runs take the tiled kernel).  Same accumulation order over K as the tiled kernels -> the same bits for every epilogue, so a
     row's embedding does not depend on the size of the batch it was encoded in."""
     from ivr_amd.linear import EPI_F32, EPI_RESID, linear
     g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
