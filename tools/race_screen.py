@@ -59,6 +59,29 @@ for (m, n, k) in shapes:
     print(f"gemm M={m} N={n} K={k}: {it + 1} launches x {len(outs)} variants reproduced" if not bad else f"gemm M={m} N={n} K={k}: mismatches so far {bad}")
 os.environ.pop("IVR_GEMM_PERS", None)
 os.environ.pop("IVR_GEMM_STAGGER", None)
+# one-query products (gemm_skinny_kernel: weight panel by LDS-DMA behind one vmcnt(0) + barrier, activations by counted register loads)
+os.environ.pop("IVR_GEMM", None)
+for (m, n, k, dt) in ((77, 512, 2048, torch.float32), (77, 2048, 512, torch.bfloat16), (50, 768, 3072, torch.bfloat16), (128, 1024, 4096, torch.float32),
+                      (1, 64, 8192, torch.bfloat16)):
+    g = torch.Generator(device="cuda").manual_seed(m + n + k)
+    x = (torch.randn((m, k), generator=g, device="cuda") * 0.7).to(dt)
+    w = (torch.randn((n, k), generator=g, device="cuda") * k ** -0.5).to(dt)
+    b = torch.randn(n, generator=g, device="cuda")
+    r0 = torch.randn((m, n), generator=g, device="cuda")
+    ref = None
+    for it in range(iters):
+        with torch.cuda.stream(side):
+            junk_b.copy_(junk_a, non_blocking=True)
+        outs = (linear(x, w, b, act=0), linear(x, w, b, epilogue=EPI_RESID, resid=r0.clone()))
+        if ref is None:
+            os.environ["IVR_GEMM_SKINNY"] = "0"
+            ref = (linear(x, w, b, act=0), linear(x, w, b, epilogue=EPI_RESID, resid=r0.clone()))       # the tiled kernel's bits
+            os.environ.pop("IVR_GEMM_SKINNY")
+        if not (torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])):
+            bad += 1
+            print(f"MISMATCH skinny M={m} N={n} K={k} {dt} iteration {it}")
+    torch.cuda.synchronize()
+    print(f"skinny gemm M={m} N={n} K={k} {str(dt).split('.')[-1]}: {iters} launches equal to the tiled kernel")
 # the large-batch candidate scan (search_scanq.hip: persistent workgroups, DMA cursors across work items, counted vmcnt)
 from ivr_amd.index import FlatIPIndex  # noqa: E402
 # ... and the small-batch scan through per-wave LDS-DMA rings (scan16_ring_kernel: at most 16 queries, d <= 512)
