@@ -445,16 +445,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 // stamps: 18.9k -> 6.3k cycles of a 55k-cycle qkv tile).  LDS images are XOR-swizzled by row: writes and reads are
 // conflict-free.
 template <typename T, int EPI, int ACT, bool SCALED = false, bool OUT8 = false, bool SKIP = false>
-__device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4][8], unsigned char *wb, int row0, int col0, int lane) {
+__device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4][8], unsigned char *wb, int row0, int col0, int lane, bool inside) {
+    // Called by every wave of the workgroup: it contains the barrier that separates the last fragment reads of the K loop from the
+    // epilogue's use of LDS.  `inside`: the wave's 64-column block lies inside N (a block is all in or all out).  The residual
+    // epilogue issues its first loads BEFORE that barrier: they go to registers, and the wait for the slowest wave then overlaps
+    // with their latency.
     const int r = lane & 15, gq = lane >> 4;
+    if (EPI != EPI_RESID) {
+        __builtin_amdgcn_s_barrier();
+        if (!inside) return;
+    }
     float4 bv[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
-        bv[nt] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + col0 + nt * 16 + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[nt] = g.bias && inside ? *reinterpret_cast<const float4 *>(g.bias + col0 + nt * 16 + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (SCALED) {                 // fp8 GEMM: per-column dequantisation scale of the weight rows
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const float4 sv = g.colscale ? *reinterpret_cast<const float4 *>(g.colscale + col0 + nt * 16 + 4 * gq) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 sv = g.colscale && inside ? *reinterpret_cast<const float4 *>(g.colscale + col0 + nt * 16 + 4 * gq) : make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
                 acc[nt][mt][0] *= sv.x;
@@ -507,15 +515,27 @@ __device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4]
             if (row0 + R < g.M) *reinterpret_cast<uint4 *>(outp + (int64_t)(row0 + R) * g.ldo) = v;
         }
     } else {
-        float *resp = g.resid + col0 + (lane & 15) * 4;
+        // Residual read-modify-write of the 128 x 64 block in four batches of 32 rows (8 float4 per lane each).  The batches are software
+        // pipelined over two register sets: both batches of the first half are in flight before the workgroup's barrier and the staging
+        // of the accumulators, those of the second half are issued as soon as a set has been stored - one partly exposed memory round
+        // trip per tile instead of four (the fragment registers of the K loop are dead here: 64 registers of residual fit beside the 128
+        // accumulators; a third set was tried and spills 13 registers, whose reloads wait for every load in flight).
+        // The block is addressed through its own buffer descriptor (wave-uniform base = its first row, 32-bit offsets, no 64-bit address
+        // arithmetic); the descriptor ends with the last valid row, so rows past M load zeros and their stores are dropped by the range
+        // check.  The row offset is added into the VGPR offset: the hardware's range check does not look at the scalar offset.
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        float *blk = g.resid + (int64_t)row0 * g.ldr + col0;
+        const int vrows = min(128, g.M - row0);
+        const auto rsR = __builtin_amdgcn_make_buffer_rsrc(blk, 0, vrows > 0 ? ((vrows - 1) * g.ldr + 64) * 4 : 0, 0x00020000);
+        const unsigned voffR = (unsigned)((lane >> 4) * g.ldr + (lane & 15) * 4) * 4u;
+        const unsigned rowB = (unsigned)g.ldr * 4u;
+        u32x4_t rvA[8], rvB[8];
+        auto loadb = [&](u32x4_t (&rv)[8], int half, int b8) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float4 rv[8];                                 // residual rows in two batches of 8 (register budget)
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int grow = min(row0 + half * 64 + it * 4 + (lane >> 4), g.M - 1);
-                rv[it] = *reinterpret_cast<const float4 *>(resp + (int64_t)grow * g.ldr);
-            }
+            for (int it = 0; it < 8; ++it)
+                rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsR, voffR + (unsigned)(half * 64 + (b8 * 8 + it) * 4) * rowB, 0, 0);
+        };
+        auto stage = [&](int half) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -525,25 +545,35 @@ __device__ __forceinline__ void wide_epilogue(const GemmArgs &g, f32x4 (&acc)[4]
                     *reinterpret_cast<float4 *>(wb + (mt * 16 + r) * 256 + chunk * 16) =
                         make_float4(a[0] + bv[nt].x, a[1] + bv[nt].y, a[2] + bv[nt].z, a[3] + bv[nt].w);
                 }
+        };
+        auto storeb = [&](const u32x4_t (&rv)[8], int half, int b8) {
 #pragma unroll
-            for (int b8 = 0; b8 < 2; ++b8) {
-                if (b8 == 1) {
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int grow = min(row0 + half * 64 + (8 + it) * 4 + (lane >> 4), g.M - 1);
-                        rv[it] = *reinterpret_cast<const float4 *>(resp + (int64_t)grow * g.ldr);
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int R = (b8 * 8 + it) * 4 + (lane >> 4), grow = row0 + half * 64 + R;
-                    const float4 v = *reinterpret_cast<const float4 *>(wb + R * 256 + (((lane & 15) ^ (R & 15)) << 4));
-                    if (grow < g.M && !(SKIP && grow % g.skip_mod == 0))
-                        *reinterpret_cast<float4 *>(resp + (int64_t)grow * g.ldr) =
-                            make_float4(rv[it].x + v.x, rv[it].y + v.y, rv[it].z + v.z, rv[it].w + v.w);
-                }
+            for (int it = 0; it < 8; ++it) {
+                const int R = (b8 * 8 + it) * 4 + (lane >> 4), grow = row0 + half * 64 + R;
+                const float4 v = *reinterpret_cast<const float4 *>(wb + R * 256 + (((lane & 15) ^ (R & 15)) << 4));
+                u32x4_t o;
+                o.x = __float_as_uint(__uint_as_float(rv[it].x) + v.x);
+                o.y = __float_as_uint(__uint_as_float(rv[it].y) + v.y);
+                o.z = __float_as_uint(__uint_as_float(rv[it].z) + v.z);
+                o.w = __float_as_uint(__uint_as_float(rv[it].w) + v.w);
+                if (!(SKIP && grow % g.skip_mod == 0))
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsR, voffR + (unsigned)(half * 64 + (b8 * 8 + it) * 4) * rowB, 0, 0);
             }
+        };
+        if (inside) {
+            loadb(rvA, 0, 0);
+            loadb(rvB, 0, 1);
         }
+        __builtin_amdgcn_s_barrier();
+        if (!inside) return;
+        stage(0);
+        storeb(rvA, 0, 0);
+        loadb(rvA, 1, 0);
+        storeb(rvB, 0, 1);
+        loadb(rvB, 1, 1);
+        stage(1);                 // the wave's LDS image is reused: its reads of the first half were issued before, LDS works in order
+        storeb(rvA, 1, 0);
+        storeb(rvB, 1, 1);
     }
 }
 
@@ -739,9 +769,8 @@ __device__ __forceinline__ void gemm_big_tile(const GemmArgs &g, const int vb, u
 #undef IVR_LGKM
 
     if (sizeof(T) == 2 && (EPI == EPI_STORE || EPI == EPI_RESID) && g.wide_epi) {
-        __builtin_amdgcn_s_barrier();                         // every wave has read its last fragments
-        if (n0 + wn * 64 < g.N)                               // N is a multiple of 64: a wave block is all in or all out
-            wide_epilogue<T, EPI, ACT, false, false, SKIP>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
+        // (contains the barrier after which every wave has read its last fragments; N is a multiple of 64: a wave block is all in or all out)
+        wide_epilogue<T, EPI, ACT, false, false, SKIP>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane, n0 + wn * 64 < g.N);
 #ifdef IVR_GEMM_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         IVR_STAMP(3)
@@ -977,9 +1006,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big8_kernel(GemmArgs g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // disabled pieces included: nothing may land in LDS after this
 #undef IVR_MMA8
-    __builtin_amdgcn_s_barrier();                             // every wave has read its last fragments
-    if (n0 + wn * 64 < g.N)
-        wide_epilogue<unsigned short, EPI, ACT, true, OUT8, SKIP>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane);
+    // (contains the barrier after which every wave has read its last fragments)
+    wide_epilogue<unsigned short, EPI, ACT, true, OUT8, SKIP>(g, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane, n0 + wn * 64 < g.N);
 }
 
 // ---------------------------------------------------------------------------------------------
