@@ -149,3 +149,11 @@ def test_random_shapes_thresholds_and_channel_orders():
         noise = synth_frames(2000 + i, 1, h, w)
         mix = ((smooth.astype(np.int32) * 3 + noise.astype(np.int32)) // 4).astype(np.uint8)
         _check(np.concatenate([smooth, noise, mix]), bgr=bool(i & 1), low=low, high=high)
+
+
+@pytest.mark.parametrize("h,w,n", [(1080, 1920, 3), (2160, 3840, 2), (1081, 1923, 2)])
+def test_full_hd_and_4k_frames(h, w, n):
+    """Real frame sizes (30 and 60 words per row, 34 and 68 tile rows, 16 sweep bands), one of them ragged in both directions: smooth
+    content has contours that span the frame, the noise frame has an edge in every tile."""
+    frames = np.concatenate([smooth_frames(7 + h, n - 1, h, w), synth_frames(8 + w, 1, h, w)])
+    _check(frames)
